@@ -1,0 +1,66 @@
+// build_internal.h -- interfaces between context.hip, bvh_build.hip and trace.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "crt/types.h"
+
+namespace crt {
+
+struct DeviceBuffer { void *ptr = nullptr; size_t bytes = 0; };
+
+struct BuildInput {            // device pointers to the uploaded arrays (reference layouts)
+    const crt_sphere *spheres; uint32_t n_spheres;
+    const crt_quad *quads;     uint32_t n_quads;
+    const crt_tri *tris;       uint32_t n_tris;
+};
+
+struct BuildState {
+    uint32_t n_prims = 0, n_pairs = 0;
+    const uint32_t *sorted_vals = nullptr;
+    // scratch
+    DeviceBuffer plo, phi, keys, vals, keys_alt, vals_alt, flag_a, flag_b, rank_a, rank_b, leaf_link, leaf_count;
+    DeviceBuffer child_l, child_r, parent, nlo, nhi, scene_bounds, temp;
+    // results (what traversal reads)
+    DeviceBuffer pairs, tri_pack, sphere_pack, quad_pack, sphere_ids, quad_ids, tri_ids;
+};
+
+bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildState &st, std::string &err);
+bool animate_tris(hipStream_t stream, uint32_t n, const crt_tri *rest, crt_tri *out, float frame, float amplitude, std::string &err);
+void free_build_state(BuildState &st);
+
+// ---- tracing (trace.hip) ----
+struct DeviceSceneHost {       // host-side mirror of DeviceScene (kept POD so context.hip need not include device headers)
+    const void *nodes; uint32_t n_pairs;
+    const void *tri_pack, *sphere_pack, *quad_pack;
+    const uint32_t *sphere_ids, *quad_ids;
+    const crt_sphere *spheres; const crt_quad *quads; const crt_tri *tris;
+    const crt_material *materials;
+    const uint8_t *tex0; uint32_t tex0_w, tex0_h, n_textures;
+};
+
+struct FrameSetup {
+    uint32_t width, height;          // imageSize()
+    uint32_t grid_w, grid_h;         // pixels actually rendered
+    uint32_t band_rank, band_world;  // this context owns the 8-row bands b with b % band_world == band_rank
+    uint32_t n_local_bands;          // bands owned
+    uint32_t max_bounces;
+    uint32_t rng_mode;
+    uint32_t instrumented;
+};
+
+struct DeviceStats { unsigned long long rays, paths, node_visits, prim_tests; };
+
+struct WavefrontState {
+    uint32_t capacity = 0;           // paths the queues can hold
+    DeviceBuffer ray_o[2], ray_d[2], thr[2], emi[2], hit, counters, pass;
+};
+
+bool launch_megakernel(hipStream_t stream, const DeviceSceneHost &sc, const FrameSetup &fs, const crt_scene_params &params,
+                       float *accum, uint32_t *hit_ids, DeviceStats *stats, std::string &err);
+bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sc, const FrameSetup &fs, const crt_scene_params &params,
+                      WavefrontState &wf, float *accum, uint32_t *hit_ids, DeviceStats *stats, std::string &err);
+void free_wavefront(WavefrontState &wf);
+
+}  // namespace crt

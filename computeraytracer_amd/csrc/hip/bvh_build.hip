@@ -1,0 +1,366 @@
+// bvh_build.hip -- device-side BVH construction (replaces the host builder
+// raytracing/src/bounding_volume_hierarchy.cpp:5-130, rows B1-B3 of SURVEY.md
+// section 8(a)).
+//
+// Pipeline (all on the context's stream, no host round trips):
+//   1. k_prim_bounds   padded AABB + centroid per primitive, scene centroid bounds (atomic min/max)
+//   2. k_morton        30-bit Morton code of the centroid
+//   3. radix sort      (code, primitive) pairs, rocPRIM
+//   4. kind ranks      exclusive scans of "is sphere" / "is quad" over the sorted order, rocPRIM
+//   5. k_pack          traversal records per kind in sorted order (tri 48 B, sphere 16 B, quad 64 B)
+//   6. k_hierarchy     Karras 2012: one thread per inner node finds its range, split and children
+//   7. k_refit_emit    bottom-up: the second thread to reach a node unions its children's boxes and
+//                      writes the node's 64-byte sibling pair (the traversal format)
+// The reference's tree is different (full-sweep SAH, threaded links); closest hits do not depend on
+// the tree because acceptance is order-independent (intersect.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "build_internal.h"
+
+namespace crt {
+
+// Order-preserving float <-> uint mapping for atomic min/max.
+__device__ __forceinline__ uint32_t enc_f(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float dec_f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
+__global__ void k_init_bounds(uint32_t *b) {
+    if (threadIdx.x < 3) b[threadIdx.x] = 0xFFFFFFFFu;       // min
+    else if (threadIdx.x < 6) b[threadIdx.x] = 0u;           // max
+}
+
+__device__ __forceinline__ void prim_box(const BuildInput &in, uint32_t g, float lo[3], float hi[3]) {
+    if (g < in.n_spheres) {
+        const crt_sphere &s = in.spheres[g];
+        float r = fabsf(s.radius);
+        for (int a = 0; a < 3; a++) { lo[a] = s.center[a] - r; hi[a] = s.center[a] + r; }
+    } else if (g < in.n_spheres + in.n_quads) {
+        const crt_quad &q = in.quads[g - in.n_spheres];
+        for (int a = 0; a < 3; a++) {
+            float c = q.corner[a], cu = c + q.u[a], cv = c + q.v[a], cuv = (c + q.u[a]) + q.v[a];
+            lo[a] = fminf(fminf(c, cu), fminf(cv, cuv));
+            hi[a] = fmaxf(fmaxf(c, cu), fmaxf(cv, cuv));
+        }
+    } else {
+        const crt_tri &t = in.tris[g - in.n_spheres - in.n_quads];
+        for (int a = 0; a < 3; a++) {
+            lo[a] = fminf(fminf(t.v0[a], t.v1[a]), t.v2[a]);
+            hi[a] = fmaxf(fmaxf(t.v0[a], t.v1[a]), t.v2[a]);
+        }
+    }
+    // Conservative padding: the slab test runs in fma form with rounded -o/d terms (intersect.h); 2^-18
+    // of the coordinate magnitude is ~64 ulp, far above its error, far below any feature size.
+    for (int a = 0; a < 3; a++) {
+        float m = fmaxf(fabsf(lo[a]), fabsf(hi[a]));
+        float p = m * 3.8146973e-6f + (hi[a] - lo[a]) * 9.5367432e-7f + 1e-30f;
+        lo[a] -= p; hi[a] += p;
+    }
+}
+
+__global__ void k_prim_bounds(BuildInput in, uint32_t n, float4 *plo, float4 *phi, uint32_t *scene_bounds) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    float c[3] = {0, 0, 0};
+    bool valid = g < n;
+    if (valid) {
+        float lo[3], hi[3];
+        prim_box(in, g, lo, hi);
+        plo[g] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        phi[g] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+        for (int a = 0; a < 3; a++) c[a] = 0.5f * lo[a] + 0.5f * hi[a];
+    }
+    // wave-level min/max of the centroids, one atomic per wave and axis
+    for (int a = 0; a < 3; a++) {
+        uint32_t mn = valid ? enc_f(c[a]) : 0xFFFFFFFFu, mx = valid ? enc_f(c[a]) : 0u;
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&scene_bounds[a], mn); atomicMax(&scene_bounds[3 + a], mx); }
+    }
+}
+
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__global__ void k_morton(uint32_t n, const float4 *plo, const float4 *phi, const uint32_t *scene_bounds,
+                         uint32_t *keys, uint32_t *vals) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    float4 lo = plo[g], hi = phi[g];
+    float c[3] = {0.5f * lo.x + 0.5f * hi.x, 0.5f * lo.y + 0.5f * hi.y, 0.5f * lo.z + 0.5f * hi.z};
+    uint32_t q[3];
+    for (int a = 0; a < 3; a++) {
+        float mn = dec_f(scene_bounds[a]), mx = dec_f(scene_bounds[3 + a]);
+        float ext = mx - mn;
+        float f = ext > 0.0f ? (c[a] - mn) / ext : 0.0f;
+        q[a] = (uint32_t)fminf(fmaxf(f * 1024.0f, 0.0f), 1023.0f);
+    }
+    keys[g] = (expand_bits10(q[0]) << 2) | (expand_bits10(q[1]) << 1) | expand_bits10(q[2]);
+    vals[g] = g;
+}
+
+__global__ void k_kind_flags(uint32_t n, const uint32_t *vals, uint32_t ns, uint32_t nq, uint32_t *is_sphere, uint32_t *is_quad) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    uint32_t g = vals[s];
+    is_sphere[s] = g < ns ? 1u : 0u;
+    is_quad[s] = (g >= ns && g < ns + nq) ? 1u : 0u;
+}
+
+// Traversal records in sorted order.  leaf_link[s] = slot inside the kind's array, leaf_count[s] = kind << 28 | 1.
+__global__ void k_pack(BuildInput in, uint32_t n, const uint32_t *vals, const uint32_t *rank_sphere, const uint32_t *rank_quad,
+                       float4 *tri_pack, float4 *sphere_pack, float4 *quad_pack, uint32_t *sphere_ids, uint32_t *quad_ids,
+                       uint32_t *tri_ids, uint32_t *leaf_link, uint32_t *leaf_count) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    uint32_t g = vals[s];
+    uint32_t rs = rank_sphere[s], rq = rank_quad[s];
+    if (g < in.n_spheres) {
+        const crt_sphere &sp = in.spheres[g];
+        sphere_pack[rs] = make_float4(sp.center[0], sp.center[1], sp.center[2], sp.radius);
+        sphere_ids[rs] = g;
+        leaf_link[s] = rs; leaf_count[s] = (CRT_ID_KIND_SPHERE << 28) | 1u;
+    } else if (g < in.n_spheres + in.n_quads) {
+        uint32_t i = g - in.n_spheres;
+        const crt_quad &q = in.quads[i];
+        float4 *o = quad_pack + 4 * (size_t)rq;
+        o[0] = make_float4(q.normal[0], q.normal[1], q.normal[2], q.d);
+        o[1] = make_float4(q.corner[0], q.corner[1], q.corner[2], q.u[0]);
+        o[2] = make_float4(q.u[1], q.u[2], q.v[0], q.v[1]);
+        o[3] = make_float4(q.v[2], q.w[0], q.w[1], q.w[2]);
+        quad_ids[rq] = i;
+        leaf_link[s] = rq; leaf_count[s] = (CRT_ID_KIND_QUAD << 28) | 1u;
+    } else {
+        uint32_t i = g - in.n_spheres - in.n_quads;
+        uint32_t rt = s - rs - rq;
+        const crt_tri &t = in.tris[i];
+        // e10 = v1 - v0, e20 = v2 - v0: the same two IEEE subtractions hit_tri performs (compute.comp:281-282)
+        float e1x = t.v1[0] - t.v0[0], e1y = t.v1[1] - t.v0[1], e1z = t.v1[2] - t.v0[2];
+        float e2x = t.v2[0] - t.v0[0], e2y = t.v2[1] - t.v0[1], e2z = t.v2[2] - t.v0[2];
+        float4 *o = tri_pack + 3 * (size_t)rt;
+        o[0] = make_float4(t.v0[0], t.v0[1], t.v0[2], e1x);
+        o[1] = make_float4(e1y, e1z, e2x, e2y);
+        o[2] = make_float4(e2z, __uint_as_float(CRT_MAKE_ID(CRT_ID_KIND_TRI, i)), 0.0f, 0.0f);
+        tri_ids[rt] = i;
+        leaf_link[s] = rt; leaf_count[s] = (CRT_ID_KIND_TRI << 28) | 1u;
+    }
+}
+
+// delta(i, j): length of the common prefix of keys i and j, ties broken by the index (Karras 2012, section 4).
+__device__ __forceinline__ int delta(const uint32_t *keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    uint32_t a = keys[i], b = keys[j];
+    if (a == b) return 32 + __clz((uint32_t)i ^ (uint32_t)j);
+    return __clz(a ^ b);
+}
+
+// Node numbering: inner i in [0, n-2], leaf j -> (n - 1) + j.  parent[] is indexed by that numbering.
+__global__ void k_hierarchy(int n, const uint32_t *keys, uint32_t *child_l, uint32_t *child_r, uint32_t *parent) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = delta(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t <= 1) break;
+    }
+    int gamma = i + s * d + min(d, 0);
+    uint32_t left = (min(i, j) == gamma) ? (uint32_t)(n - 1 + gamma) : (uint32_t)gamma;
+    uint32_t right = (max(i, j) == gamma + 1) ? (uint32_t)(n - 1 + gamma + 1) : (uint32_t)(gamma + 1);
+    child_l[i] = left; child_r[i] = right;
+    parent[left] = (uint32_t)i; parent[right] = (uint32_t)i;
+    if (i == 0) parent[0] = 0xFFFFFFFFu;
+}
+
+// Child record inside its parent's pair.
+__device__ __forceinline__ void write_child(float4 *pair_half, int n, uint32_t child, float4 lo, float4 hi,
+                                            const uint32_t *leaf_link, const uint32_t *leaf_count) {
+    uint32_t link, count;
+    if (child >= (uint32_t)(n - 1)) { uint32_t s = child - (uint32_t)(n - 1); link = leaf_link[s]; count = leaf_count[s]; }
+    else { link = child; count = 0u; }
+    pair_half[0] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(link));
+    pair_half[1] = make_float4(hi.x, hi.y, hi.z, __uint_as_float(count));
+}
+
+// Bottom-up refit.  One thread per leaf climbs; at each inner node the first arrival stops, the second
+// (which therefore knows both subtrees are finished) computes the node.  Cross-workgroup hand-off of
+// the sibling's box: stores, agent-scope fence (release), returning atomic; the winner fences again
+// (acquire: invalidates this CU's L1) before loading what the other thread stored.
+__global__ void k_refit_emit(int n, const uint32_t *vals, const float4 *plo, const float4 *phi,
+                             const uint32_t *child_l, const uint32_t *child_r, const uint32_t *parent,
+                             const uint32_t *leaf_link, const uint32_t *leaf_count,
+                             float4 *nlo, float4 *nhi, uint32_t *flags, float4 *pairs) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t node = (uint32_t)(n - 1 + j);
+    uint32_t g = vals[j];
+    float4 lo = plo[g], hi = phi[g];
+    nlo[node] = lo; nhi[node] = hi;
+    for (;;) {
+        uint32_t p = parent[node];
+        if (p == 0xFFFFFFFFu) break;
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t old = atomicAdd(&flags[p], 1u);
+        if (old == 0u) break;
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t cl = child_l[p], cr = child_r[p];
+        uint32_t sib = cl == node ? cr : cl;
+        float4 slo = nlo[sib], shi = nhi[sib];
+        float4 l_lo = cl == node ? lo : slo, l_hi = cl == node ? hi : shi;
+        float4 r_lo = cl == node ? slo : lo, r_hi = cl == node ? shi : hi;
+        write_child(pairs + 4 * (size_t)p, n, cl, l_lo, l_hi, leaf_link, leaf_count);
+        write_child(pairs + 4 * (size_t)p + 2, n, cr, r_lo, r_hi, leaf_link, leaf_count);
+        lo = make_float4(fminf(l_lo.x, r_lo.x), fminf(l_lo.y, r_lo.y), fminf(l_lo.z, r_lo.z), 0.0f);
+        hi = make_float4(fmaxf(l_hi.x, r_hi.x), fmaxf(l_hi.y, r_hi.y), fmaxf(l_hi.z, r_hi.z), 0.0f);
+        nlo[p] = lo; nhi[p] = hi;
+        node = p;
+    }
+}
+
+// n == 1: a single leaf beside an empty leaf (count field = kind bits only, zero primitives).
+__global__ void k_single_pair(const uint32_t *vals, const float4 *plo, const float4 *phi, const uint32_t *leaf_link,
+                              const uint32_t *leaf_count, float4 *pairs) {
+    if (threadIdx.x != 0) return;
+    uint32_t g = vals[0];
+    float4 lo = plo[g], hi = phi[g];
+    pairs[0] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(leaf_link[0]));
+    pairs[1] = make_float4(hi.x, hi.y, hi.z, __uint_as_float(leaf_count[0]));
+    pairs[2] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+    pairs[3] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(CRT_ID_KIND_TRI << 28));
+}
+
+// Config 5 animation: y = rest_y + amplitude * sin(frame + x + z) on every triangle vertex.
+__global__ void k_animate_tris(uint32_t n, const crt_tri *rest, crt_tri *out, float frame, float amplitude) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    crt_tri t = rest[i];
+    t.v0[1] = t.v0[1] + amplitude * __sinf(frame + t.v0[0] + t.v0[2]);
+    t.v1[1] = t.v1[1] + amplitude * __sinf(frame + t.v1[0] + t.v1[2]);
+    t.v2[1] = t.v2[1] + amplitude * __sinf(frame + t.v2[0] + t.v2[2]);
+    out[i] = t;
+}
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return false; } } while (0)
+
+static bool ensure(DeviceBuffer &b, size_t bytes, std::string &err) {
+    if (b.bytes >= bytes && b.ptr) return true;
+    if (b.ptr) { hipError_t e = hipFree(b.ptr); (void)e; b.ptr = nullptr; b.bytes = 0; }
+    size_t want = bytes < 256 ? 256 : bytes;
+    HIP_TRY(hipMalloc(&b.ptr, want));
+    b.bytes = want;
+    return true;
+}
+
+bool animate_tris(hipStream_t stream, uint32_t n, const crt_tri *rest, crt_tri *out, float frame, float amplitude, std::string &err) {
+    if (n == 0) return true;
+    hipLaunchKernelGGL(k_animate_tris, dim3((n + 255) / 256), dim3(256), 0, stream, n, rest, out, frame, amplitude);
+    HIP_TRY(hipGetLastError());
+    return true;
+}
+
+bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildState &st, std::string &err) {
+    const uint32_t n = in.n_spheres + in.n_quads + in.n_tris;
+    st.n_prims = n;
+    st.n_pairs = n == 0 ? 0 : (n == 1 ? 1 : n - 1);
+    if (n == 0) return true;
+    const uint32_t blocks = (n + 255) / 256;
+    const size_t n4 = (size_t)n * sizeof(float4);
+    if (!ensure(st.plo, n4, err) || !ensure(st.phi, n4, err)) return false;
+    if (!ensure(st.keys, (size_t)n * 4, err) || !ensure(st.vals, (size_t)n * 4, err)) return false;
+    if (!ensure(st.keys_alt, (size_t)n * 4, err) || !ensure(st.vals_alt, (size_t)n * 4, err)) return false;
+    if (!ensure(st.flag_a, (size_t)n * 4, err) || !ensure(st.flag_b, (size_t)n * 4, err)) return false;
+    if (!ensure(st.rank_a, (size_t)n * 4, err) || !ensure(st.rank_b, (size_t)n * 4, err)) return false;
+    if (!ensure(st.leaf_link, (size_t)n * 4, err) || !ensure(st.leaf_count, (size_t)n * 4, err)) return false;
+    if (!ensure(st.child_l, (size_t)n * 4, err) || !ensure(st.child_r, (size_t)n * 4, err)) return false;
+    if (!ensure(st.parent, (size_t)(2 * (size_t)n) * 4, err)) return false;
+    if (!ensure(st.nlo, 2 * n4, err) || !ensure(st.nhi, 2 * n4, err)) return false;
+    if (!ensure(st.scene_bounds, 64, err)) return false;
+    if (!ensure(st.pairs, (size_t)st.n_pairs * 4 * sizeof(float4), err)) return false;
+    if (!ensure(st.tri_pack, (size_t)in.n_tris * 3 * sizeof(float4), err)) return false;
+    if (!ensure(st.sphere_pack, (size_t)in.n_spheres * sizeof(float4), err)) return false;
+    if (!ensure(st.quad_pack, (size_t)in.n_quads * 4 * sizeof(float4), err)) return false;
+    if (!ensure(st.sphere_ids, (size_t)in.n_spheres * 4, err) || !ensure(st.quad_ids, (size_t)in.n_quads * 4, err)) return false;
+    if (!ensure(st.tri_ids, (size_t)in.n_tris * 4, err)) return false;
+
+    // temp storage for rocPRIM (sized for the larger of sort and scan)
+    size_t sort_bytes = 0, scan_bytes = 0;
+    rocprim::double_buffer<uint32_t> dkeys((uint32_t *)st.keys.ptr, (uint32_t *)st.keys_alt.ptr);
+    rocprim::double_buffer<uint32_t> dvals((uint32_t *)st.vals.ptr, (uint32_t *)st.vals_alt.ptr);
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, dkeys, dvals, n, 0, 30, stream));
+    HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t *)st.flag_a.ptr, (uint32_t *)st.rank_a.ptr, 0u, n,
+                                    rocprim::plus<uint32_t>(), stream));
+    if (!ensure(st.temp, std::max(sort_bytes, scan_bytes), err)) return false;
+
+    hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, (uint32_t *)st.scene_bounds.ptr);
+    hipLaunchKernelGGL(k_prim_bounds, dim3(blocks), dim3(256), 0, stream, in, n, (float4 *)st.plo.ptr, (float4 *)st.phi.ptr,
+                       (uint32_t *)st.scene_bounds.ptr);
+    hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, (const float4 *)st.plo.ptr, (const float4 *)st.phi.ptr,
+                       (const uint32_t *)st.scene_bounds.ptr, (uint32_t *)st.keys.ptr, (uint32_t *)st.vals.ptr);
+    HIP_TRY(hipGetLastError());
+    size_t tb = st.temp.bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(st.temp.ptr, tb, dkeys, dvals, n, 0, 30, stream));
+    const uint32_t *keys = dkeys.current(), *vals = dvals.current();
+    st.sorted_vals = vals;
+
+    hipLaunchKernelGGL(k_kind_flags, dim3(blocks), dim3(256), 0, stream, n, vals, in.n_spheres, in.n_quads,
+                       (uint32_t *)st.flag_a.ptr, (uint32_t *)st.flag_b.ptr);
+    tb = st.temp.bytes;
+    HIP_TRY(rocprim::exclusive_scan(st.temp.ptr, tb, (uint32_t *)st.flag_a.ptr, (uint32_t *)st.rank_a.ptr, 0u, n,
+                                    rocprim::plus<uint32_t>(), stream));
+    tb = st.temp.bytes;
+    HIP_TRY(rocprim::exclusive_scan(st.temp.ptr, tb, (uint32_t *)st.flag_b.ptr, (uint32_t *)st.rank_b.ptr, 0u, n,
+                                    rocprim::plus<uint32_t>(), stream));
+    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, stream, in, n, vals, (const uint32_t *)st.rank_a.ptr,
+                       (const uint32_t *)st.rank_b.ptr, (float4 *)st.tri_pack.ptr, (float4 *)st.sphere_pack.ptr,
+                       (float4 *)st.quad_pack.ptr, (uint32_t *)st.sphere_ids.ptr, (uint32_t *)st.quad_ids.ptr,
+                       (uint32_t *)st.tri_ids.ptr, (uint32_t *)st.leaf_link.ptr, (uint32_t *)st.leaf_count.ptr);
+    HIP_TRY(hipGetLastError());
+
+    if (n == 1) {
+        hipLaunchKernelGGL(k_single_pair, dim3(1), dim3(64), 0, stream, vals, (const float4 *)st.plo.ptr, (const float4 *)st.phi.ptr,
+                           (const uint32_t *)st.leaf_link.ptr, (const uint32_t *)st.leaf_count.ptr, (float4 *)st.pairs.ptr);
+        HIP_TRY(hipGetLastError());
+        return true;
+    }
+    hipLaunchKernelGGL(k_hierarchy, dim3((n - 1 + 255) / 256), dim3(256), 0, stream, (int)n, keys, (uint32_t *)st.child_l.ptr,
+                       (uint32_t *)st.child_r.ptr, (uint32_t *)st.parent.ptr);
+    HIP_TRY(hipMemsetAsync(st.flag_a.ptr, 0, (size_t)n * 4, stream));
+    hipLaunchKernelGGL(k_refit_emit, dim3(blocks), dim3(256), 0, stream, (int)n, vals, (const float4 *)st.plo.ptr,
+                       (const float4 *)st.phi.ptr, (const uint32_t *)st.child_l.ptr, (const uint32_t *)st.child_r.ptr,
+                       (const uint32_t *)st.parent.ptr, (const uint32_t *)st.leaf_link.ptr, (const uint32_t *)st.leaf_count.ptr,
+                       (float4 *)st.nlo.ptr, (float4 *)st.nhi.ptr, (uint32_t *)st.flag_a.ptr, (float4 *)st.pairs.ptr);
+    HIP_TRY(hipGetLastError());
+    (void)flags;
+    return true;
+}
+
+void free_build_state(BuildState &st) {
+    DeviceBuffer *all[] = {&st.plo, &st.phi, &st.keys, &st.vals, &st.keys_alt, &st.vals_alt, &st.flag_a, &st.flag_b, &st.rank_a,
+                           &st.rank_b, &st.leaf_link, &st.leaf_count, &st.child_l, &st.child_r, &st.parent, &st.nlo, &st.nhi,
+                           &st.scene_bounds, &st.temp, &st.pairs, &st.tri_pack, &st.sphere_pack, &st.quad_pack, &st.sphere_ids,
+                           &st.quad_ids, &st.tri_ids};
+    for (DeviceBuffer *b : all) if (b->ptr) { hipError_t e = hipFree(b->ptr); (void)e; b->ptr = nullptr; b->bytes = 0; }
+}
+
+}  // namespace crt

@@ -1,0 +1,402 @@
+// context.hip -- the C ABI of include/crt/abi.h on top of the HIP kernels.
+// Replaces the descriptor/dispatch surface of VulkanEngine (engine/src/vk_engine.cpp:
+// init_descriptors :1116-1237, upload_buffer :656-690, draw :1370-1498).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "build_internal.h"
+#include "crt/abi.h"
+
+using namespace crt;
+
+struct crt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::string error;
+    crt_config cfg{};
+    bool configured = false, have_scene = false, have_bvh = false, timing_pending = false;
+    // scene (reference layouts, input order)
+    DeviceBuffer spheres, quads, tris, tris_rest, materials, tex0;
+    uint32_t n_spheres = 0, n_quads = 0, n_tris = 0, n_materials = 0, n_textures = 0, tex0_w = 0, tex0_h = 0;
+    bool animated = false;
+    BuildState build;
+    // image
+    DeviceBuffer accum, hit_ids, stats;
+    uint32_t grid_w = 0, grid_h = 0, n_local_bands = 0, local_rows = 0;
+    WavefrontState wf;
+    int instrumented = 0;
+    double last_render_ms = 0.0, last_build_ms = 0.0;
+};
+
+namespace {
+
+int fail(crt_context *ctx, int code, const std::string &msg) { if (ctx) ctx->error = msg; return code; }
+
+#define CTX_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(ctx, CRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+int bind(crt_context *ctx) {
+    if (!ctx) return CRT_ERR_INVALID;
+    CTX_HIP(hipSetDevice(ctx->device));
+    return CRT_OK;
+}
+
+int alloc(crt_context *ctx, DeviceBuffer &b, size_t bytes) {
+    if (b.ptr && b.bytes >= bytes) return CRT_OK;
+    if (b.ptr) { CTX_HIP(hipFree(b.ptr)); b.ptr = nullptr; b.bytes = 0; }
+    size_t want = bytes < 256 ? 256 : bytes;
+    CTX_HIP(hipMalloc(&b.ptr, want));
+    b.bytes = want;
+    return CRT_OK;
+}
+
+void release(DeviceBuffer &b) { if (b.ptr) { hipError_t e = hipFree(b.ptr); (void)e; } b.ptr = nullptr; b.bytes = 0; }
+
+int upload(crt_context *ctx, DeviceBuffer &b, const void *src, size_t bytes) {
+    int rc = alloc(ctx, b, bytes);
+    if (rc) return rc;
+    if (bytes) CTX_HIP(hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice));   // synchronous, like immediate_submit + fence wait
+    return CRT_OK;
+}
+
+uint32_t local_bands(uint32_t grid_h, uint32_t rank, uint32_t world) {
+    uint32_t nb = (grid_h + 7) / 8;
+    if (world <= 1) return nb;
+    return nb > rank ? (nb - rank + world - 1) / world : 0;
+}
+
+DeviceSceneHost scene_view(const crt_context *ctx) {
+    DeviceSceneHost s{};
+    s.nodes = ctx->build.pairs.ptr; s.n_pairs = ctx->build.n_pairs;
+    s.tri_pack = ctx->build.tri_pack.ptr; s.sphere_pack = ctx->build.sphere_pack.ptr; s.quad_pack = ctx->build.quad_pack.ptr;
+    s.sphere_ids = (const uint32_t *)ctx->build.sphere_ids.ptr; s.quad_ids = (const uint32_t *)ctx->build.quad_ids.ptr;
+    s.spheres = (const crt_sphere *)ctx->spheres.ptr; s.quads = (const crt_quad *)ctx->quads.ptr; s.tris = (const crt_tri *)ctx->tris.ptr;
+    s.materials = (const crt_material *)ctx->materials.ptr;
+    s.tex0 = (const uint8_t *)ctx->tex0.ptr; s.tex0_w = ctx->tex0_w; s.tex0_h = ctx->tex0_h; s.n_textures = ctx->n_textures;
+    return s;
+}
+
+FrameSetup frame_setup(const crt_context *ctx) {
+    FrameSetup fs{};
+    fs.width = ctx->cfg.width; fs.height = ctx->cfg.height; fs.grid_w = ctx->grid_w; fs.grid_h = ctx->grid_h;
+    fs.band_rank = ctx->cfg.band_world > 1 ? ctx->cfg.band_rank : 0;
+    fs.band_world = ctx->cfg.band_world > 1 ? ctx->cfg.band_world : 1;
+    fs.n_local_bands = ctx->n_local_bands;
+    fs.max_bounces = ctx->cfg.max_bounces ? ctx->cfg.max_bounces : 10;   // MAX_BOUNCES, compute.comp:16
+    fs.rng_mode = ctx->cfg.rng_mode;
+    fs.instrumented = (uint32_t)ctx->instrumented;
+    return fs;
+}
+
+int finish_timing(crt_context *ctx) {
+    if (!ctx->timing_pending) return CRT_OK;
+    CTX_HIP(hipEventSynchronize(ctx->ev_stop));
+    float ms = 0.0f;
+    CTX_HIP(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    ctx->last_render_ms = ms;
+    ctx->timing_pending = false;
+    return CRT_OK;
+}
+
+int dispatch_one(crt_context *ctx, const crt_scene_params &p) {
+    std::string err;
+    DeviceSceneHost sc = scene_view(ctx);
+    FrameSetup fs = frame_setup(ctx);
+    bool ok;
+    if (ctx->cfg.tracer == CRT_TRACER_WAVEFRONT)
+        ok = launch_wavefront(ctx->stream, sc, fs, p, ctx->wf, (float *)ctx->accum.ptr, (uint32_t *)ctx->hit_ids.ptr,
+                              (DeviceStats *)ctx->stats.ptr, err);
+    else
+        ok = launch_megakernel(ctx->stream, sc, fs, p, (float *)ctx->accum.ptr, (uint32_t *)ctx->hit_ids.ptr,
+                               (DeviceStats *)ctx->stats.ptr, err);
+    if (!ok) return fail(ctx, CRT_ERR_HIP, err);
+    return CRT_OK;
+}
+
+int ready_to_render(crt_context *ctx) {
+    if (!ctx->configured) return fail(ctx, CRT_ERR_INVALID, "crt_configure has not been called");
+    if (!ctx->have_scene) return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload has not been called");
+    if (!ctx->have_bvh) return fail(ctx, CRT_ERR_INVALID, "crt_bvh_build has not been called for the current scene");
+    return CRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *crt_version(void) { return "crt-mi355x 0.1 (gfx950)"; }
+
+int crt_create(int device, crt_context **out) {
+    if (!out) return CRT_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return CRT_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return CRT_ERR_NO_DEVICE;
+    crt_context *ctx = new crt_context();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+        delete ctx;
+        return CRT_ERR_HIP;
+    }
+    if (hipMalloc(&ctx->stats.ptr, 256) != hipSuccess || hipMemset(ctx->stats.ptr, 0, 256) != hipSuccess) { delete ctx; return CRT_ERR_HIP; }
+    ctx->stats.bytes = 256;
+    *out = ctx;
+    return CRT_OK;
+}
+
+void crt_destroy(crt_context *ctx) {
+    if (!ctx) return;
+    if (hipSetDevice(ctx->device) == hipSuccess) {
+        hipError_t e = hipStreamSynchronize(ctx->stream); (void)e;
+        DeviceBuffer *all[] = {&ctx->spheres, &ctx->quads, &ctx->tris, &ctx->tris_rest, &ctx->materials, &ctx->tex0, &ctx->accum, &ctx->hit_ids, &ctx->stats};
+        for (DeviceBuffer *b : all) release(*b);
+        free_build_state(ctx->build);
+        free_wavefront(ctx->wf);
+        e = hipEventDestroy(ctx->ev_start); e = hipEventDestroy(ctx->ev_stop); e = hipStreamDestroy(ctx->stream); (void)e;
+    }
+    delete ctx;
+}
+
+const char *crt_last_error(const crt_context *ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+int crt_configure(crt_context *ctx, const crt_config *cfg) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!cfg || cfg->width == 0 || cfg->height == 0) return fail(ctx, CRT_ERR_INVALID, "crt_configure: width/height must be non-zero");
+    if ((uint64_t)cfg->width * cfg->height >= (1ull << 31)) return fail(ctx, CRT_ERR_INVALID, "crt_configure: image too large");
+    if (cfg->rng_mode > CRT_RNG_PCG || cfg->tracer > CRT_TRACER_WAVEFRONT) return fail(ctx, CRT_ERR_INVALID, "crt_configure: unknown rng_mode/tracer");
+    if (cfg->band_world > 1 && cfg->band_rank >= cfg->band_world) return fail(ctx, CRT_ERR_INVALID, "crt_configure: band_rank >= band_world");
+    CTX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->cfg = *cfg;
+    bool full = (cfg->flags & CRT_FLAG_FULL_IMAGE) != 0;
+    ctx->grid_w = full ? cfg->width : (cfg->width / 8) * 8;      // dispatch(W/8, H/8, 1), vk_engine.cpp:1435
+    ctx->grid_h = full ? cfg->height : (cfg->height / 8) * 8;
+    uint32_t world = cfg->band_world > 1 ? cfg->band_world : 1, rank = cfg->band_world > 1 ? cfg->band_rank : 0;
+    ctx->n_local_bands = local_bands(ctx->grid_h, rank, world);
+    // the packed band buffer always holds whole 8-row bands; when world == 1 it is exactly the image
+    // (rows above grid_h, if any, stay zero)
+    uint32_t rows = ctx->n_local_bands * 8;
+    if (world == 1 && rows < cfg->height) rows = cfg->height;
+    ctx->local_rows = rows;
+    size_t px = (size_t)rows * cfg->width;
+    rc = alloc(ctx, ctx->accum, px * 16); if (rc) return rc;
+    rc = alloc(ctx, ctx->hit_ids, px * 4); if (rc) return rc;
+    CTX_HIP(hipMemsetAsync(ctx->accum.ptr, 0, px * 16, ctx->stream));
+    CTX_HIP(hipMemsetAsync(ctx->hit_ids.ptr, 0xFF, px * 4, ctx->stream));
+    CTX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->configured = true;
+    return CRT_OK;
+}
+
+int crt_scene_upload(crt_context *ctx, const crt_scene_desc *s) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!s) return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload: null scene");
+    if ((s->n_spheres && !s->spheres) || (s->n_quads && !s->quads) || (s->n_tris && !s->tris) || (s->n_materials && !s->materials) ||
+        (s->n_textures && !s->textures))
+        return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload: a non-empty array has a null pointer");
+    if (s->n_spheres >= (1u << 30) || s->n_quads >= (1u << 30) || s->n_tris >= (1u << 30) - 1)
+        return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload: more than 2^30 primitives of one kind");
+    // every primitive's material index must be in range: the kernels index the material array unchecked
+    for (uint32_t i = 0; i < s->n_spheres; i++) if (s->spheres[i].materialIndex >= s->n_materials) return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload: sphere material index out of range");
+    for (uint32_t i = 0; i < s->n_quads; i++) if (s->quads[i].materialIndex >= s->n_materials) return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload: quad material index out of range");
+    for (uint32_t i = 0; i < s->n_tris; i++) if (s->tris[i].materialIndex >= s->n_materials) return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload: triangle material index out of range");
+    for (uint32_t i = 0; i < s->n_textures; i++)
+        if (!s->textures[i].rgba8 || s->textures[i].width == 0 || s->textures[i].height == 0) return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload: empty texture");
+    CTX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->have_scene = false; ctx->have_bvh = false; ctx->animated = false;
+    if ((rc = upload(ctx, ctx->spheres, s->spheres, (size_t)s->n_spheres * sizeof(crt_sphere)))) return rc;
+    if ((rc = upload(ctx, ctx->quads, s->quads, (size_t)s->n_quads * sizeof(crt_quad)))) return rc;
+    if ((rc = upload(ctx, ctx->tris, s->tris, (size_t)s->n_tris * sizeof(crt_tri)))) return rc;
+    if ((rc = upload(ctx, ctx->materials, s->materials, (size_t)s->n_materials * sizeof(crt_material)))) return rc;
+    ctx->n_spheres = s->n_spheres; ctx->n_quads = s->n_quads; ctx->n_tris = s->n_tris; ctx->n_materials = s->n_materials;
+    ctx->n_textures = s->n_textures; ctx->tex0_w = ctx->tex0_h = 0;
+    if (s->n_textures) {
+        // the shader samples textures[0] only (compute.comp:386-387), so that is the one resident texture
+        const crt_texture &t = s->textures[0];
+        if ((rc = upload(ctx, ctx->tex0, t.rgba8, (size_t)t.width * t.height * 4))) return rc;
+        ctx->tex0_w = t.width; ctx->tex0_h = t.height;
+    }
+    ctx->have_scene = true;
+    return CRT_OK;
+}
+
+int crt_bvh_build(crt_context *ctx, uint32_t flags, float *build_ms) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!ctx->have_scene) return fail(ctx, CRT_ERR_INVALID, "crt_bvh_build: no scene uploaded");
+    rc = finish_timing(ctx); if (rc) return rc;
+    BuildInput in{(const crt_sphere *)ctx->spheres.ptr, ctx->n_spheres, (const crt_quad *)ctx->quads.ptr, ctx->n_quads,
+                  (const crt_tri *)ctx->tris.ptr, ctx->n_tris};
+    std::string err;
+    hipEvent_t e0, e1;
+    CTX_HIP(hipEventCreate(&e0)); CTX_HIP(hipEventCreate(&e1));
+    // warm the allocations (first build at a size allocates; the timed region below then only launches)
+    CTX_HIP(hipEventRecord(e0, ctx->stream));
+    bool ok = build_bvh(ctx->stream, in, flags, ctx->build, err);
+    CTX_HIP(hipEventRecord(e1, ctx->stream));
+    if (!ok) { hipError_t e = hipEventDestroy(e0); e = hipEventDestroy(e1); (void)e; return fail(ctx, CRT_ERR_HIP, "crt_bvh_build: " + err); }
+    CTX_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    CTX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    CTX_HIP(hipEventDestroy(e0)); CTX_HIP(hipEventDestroy(e1));
+    ctx->last_build_ms = ms;
+    if (build_ms) *build_ms = ms;
+    ctx->have_bvh = true;
+    return CRT_OK;
+}
+
+int crt_tris_update(crt_context *ctx, const crt_tri *tris, uint32_t first, uint32_t count) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!ctx->have_scene) return fail(ctx, CRT_ERR_INVALID, "crt_tris_update: no scene uploaded");
+    if (!tris || (uint64_t)first + count > ctx->n_tris) return fail(ctx, CRT_ERR_INVALID, "crt_tris_update: range outside the uploaded triangles");
+    CTX_HIP(hipStreamSynchronize(ctx->stream));
+    CTX_HIP(hipMemcpy((crt_tri *)ctx->tris.ptr + first, tris, (size_t)count * sizeof(crt_tri), hipMemcpyDefault));
+    ctx->have_bvh = false;
+    return CRT_OK;
+}
+
+int crt_tris_animate(crt_context *ctx, float frame, float amplitude) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!ctx->have_scene) return fail(ctx, CRT_ERR_INVALID, "crt_tris_animate: no scene uploaded");
+    size_t bytes = (size_t)ctx->n_tris * sizeof(crt_tri);
+    if (!ctx->animated) {      // keep the rest pose
+        rc = alloc(ctx, ctx->tris_rest, bytes); if (rc) return rc;
+        CTX_HIP(hipMemcpyAsync(ctx->tris_rest.ptr, ctx->tris.ptr, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->animated = true;
+    }
+    std::string err;
+    if (!animate_tris(ctx->stream, ctx->n_tris, (const crt_tri *)ctx->tris_rest.ptr, (crt_tri *)ctx->tris.ptr, frame, amplitude, err))
+        return fail(ctx, CRT_ERR_HIP, "crt_tris_animate: " + err);
+    ctx->have_bvh = false;
+    return CRT_OK;
+}
+
+int crt_dispatch(crt_context *ctx, const crt_scene_params *params) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!params) return fail(ctx, CRT_ERR_INVALID, "crt_dispatch: null params");
+    if ((rc = ready_to_render(ctx))) return rc;
+    if ((rc = finish_timing(ctx))) return rc;
+    CTX_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
+    rc = dispatch_one(ctx, *params);
+    CTX_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->timing_pending = true;
+    return rc;
+}
+
+int crt_render(crt_context *ctx, const crt_scene_params *params, uint32_t first_iteration, uint32_t n_iterations, const float *seeds) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!params || (n_iterations && !seeds)) return fail(ctx, CRT_ERR_INVALID, "crt_render: null params/seeds");
+    if ((rc = ready_to_render(ctx))) return rc;
+    if ((rc = finish_timing(ctx))) return rc;
+    CTX_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
+    crt_scene_params p = *params;
+    for (uint32_t i = 0; i < n_iterations && rc == CRT_OK; i++) {
+        p.camera.iteration = (float)(first_iteration + i);
+        p.camera.seed = seeds[i];
+        rc = dispatch_one(ctx, p);
+    }
+    CTX_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->timing_pending = true;
+    return rc;
+}
+
+int crt_sync(crt_context *ctx) {
+    int rc = bind(ctx); if (rc) return rc;
+    CTX_HIP(hipStreamSynchronize(ctx->stream));
+    return finish_timing(ctx);
+}
+
+uint32_t crt_band_rows(uint32_t height, uint32_t band_rank, uint32_t band_world, uint32_t *rows) {
+    uint32_t world = band_world > 1 ? band_world : 1, rank = band_world > 1 ? band_rank : 0, n = 0;
+    for (uint32_t y = 0; y < height; y++)
+        if ((y / 8) % world == rank) { if (rows) rows[n] = y; n++; }
+    return n;
+}
+
+static int read_banded(crt_context *ctx, const DeviceBuffer &src, void *dst, size_t elem_bytes, int fill) {
+    uint32_t W = ctx->cfg.width, H = ctx->cfg.height;
+    uint32_t world = ctx->cfg.band_world > 1 ? ctx->cfg.band_world : 1, rank = ctx->cfg.band_world > 1 ? ctx->cfg.band_rank : 0;
+    size_t row_bytes = (size_t)W * elem_bytes;
+    CTX_HIP(hipStreamSynchronize(ctx->stream));
+    if (world == 1) {
+        CTX_HIP(hipMemcpy(dst, src.ptr, row_bytes * H, hipMemcpyDeviceToHost));
+        return CRT_OK;
+    }
+    std::vector<uint8_t> tmp(row_bytes * ctx->local_rows);
+    if (!tmp.empty()) CTX_HIP(hipMemcpy(tmp.data(), src.ptr, tmp.size(), hipMemcpyDeviceToHost));
+    memset(dst, fill, row_bytes * H);
+    for (uint32_t y = 0; y < H; y++) {
+        uint32_t band = y / 8;
+        if (band % world != rank) continue;
+        uint32_t prow = (band / world) * 8 + (y % 8);
+        if (prow < ctx->local_rows) memcpy((uint8_t *)dst + row_bytes * y, tmp.data() + row_bytes * prow, row_bytes);
+    }
+    return CRT_OK;
+}
+
+int crt_image_read(crt_context *ctx, float *rgba, size_t n_floats) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!ctx->configured) return fail(ctx, CRT_ERR_INVALID, "crt_image_read: not configured");
+    if (!rgba || n_floats != (size_t)ctx->cfg.width * ctx->cfg.height * 4) return fail(ctx, CRT_ERR_INVALID, "crt_image_read: buffer must hold width*height*4 floats");
+    rc = read_banded(ctx, ctx->accum, rgba, 16, 0);
+    if (rc) return rc;
+    return finish_timing(ctx);
+}
+
+int crt_hit_ids_read(crt_context *ctx, uint32_t *ids, size_t n_ids) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!ctx->configured) return fail(ctx, CRT_ERR_INVALID, "crt_hit_ids_read: not configured");
+    if (!ids || n_ids != (size_t)ctx->cfg.width * ctx->cfg.height) return fail(ctx, CRT_ERR_INVALID, "crt_hit_ids_read: buffer must hold width*height ids");
+    rc = read_banded(ctx, ctx->hit_ids, ids, 4, 0xFF);
+    if (rc) return rc;
+    return finish_timing(ctx);
+}
+
+int crt_image_device_ptr(crt_context *ctx, void **device_ptr, size_t *n_bytes) {
+    if (!ctx || !device_ptr || !n_bytes) return CRT_ERR_INVALID;
+    if (!ctx->configured) return fail(ctx, CRT_ERR_INVALID, "crt_image_device_ptr: not configured");
+    *device_ptr = ctx->accum.ptr;
+    *n_bytes = (size_t)ctx->local_rows * ctx->cfg.width * 16;
+    return CRT_OK;
+}
+
+int crt_stats_read(crt_context *ctx, crt_stats *out) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!out) return fail(ctx, CRT_ERR_INVALID, "crt_stats_read: null output");
+    CTX_HIP(hipStreamSynchronize(ctx->stream));
+    if ((rc = finish_timing(ctx))) return rc;
+    DeviceStats ds;
+    CTX_HIP(hipMemcpy(&ds, ctx->stats.ptr, sizeof ds, hipMemcpyDeviceToHost));
+    out->rays = ds.rays; out->paths = ds.paths; out->node_visits = ds.node_visits; out->prim_tests = ds.prim_tests;
+    out->last_render_ms = ctx->last_render_ms; out->last_build_ms = ctx->last_build_ms;
+    return CRT_OK;
+}
+
+int crt_stats_reset(crt_context *ctx) {
+    int rc = bind(ctx); if (rc) return rc;
+    CTX_HIP(hipMemsetAsync(ctx->stats.ptr, 0, sizeof(DeviceStats), ctx->stream));
+    return CRT_OK;
+}
+
+int crt_set_instrumented(crt_context *ctx, int on) {
+    if (!ctx) return CRT_ERR_INVALID;
+    ctx->instrumented = on ? 1 : 0;
+    return CRT_OK;
+}
+
+int crt_bvh_read(crt_context *ctx, crt_bvh_node *nodes, uint32_t *n_nodes, uint32_t *sphere_ids, uint32_t *quad_ids, uint32_t *tri_ids) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!ctx->have_bvh) return fail(ctx, CRT_ERR_INVALID, "crt_bvh_read: no BVH built");
+    if (!n_nodes) return fail(ctx, CRT_ERR_INVALID, "crt_bvh_read: null n_nodes");
+    *n_nodes = ctx->build.n_pairs * 2;
+    CTX_HIP(hipStreamSynchronize(ctx->stream));
+    if (nodes && ctx->build.n_pairs) CTX_HIP(hipMemcpy(nodes, ctx->build.pairs.ptr, (size_t)ctx->build.n_pairs * 64, hipMemcpyDeviceToHost));
+    if (sphere_ids && ctx->n_spheres) CTX_HIP(hipMemcpy(sphere_ids, ctx->build.sphere_ids.ptr, (size_t)ctx->n_spheres * 4, hipMemcpyDeviceToHost));
+    if (quad_ids && ctx->n_quads) CTX_HIP(hipMemcpy(quad_ids, ctx->build.quad_ids.ptr, (size_t)ctx->n_quads * 4, hipMemcpyDeviceToHost));
+    if (tri_ids && ctx->n_tris) CTX_HIP(hipMemcpy(tri_ids, ctx->build.tri_ids.ptr, (size_t)ctx->n_tris * 4, hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+// intersect.h -- closest-hit search over the build's pair BVH (R5-R9 of
+// SURVEY.md section 8(a)) and reconstruction of the shader's HitRecord.
+//
+// Traversal keeps only (t, id).  Acceptance is order-independent: a candidate
+// replaces the current hit when tNear < t and (t < best or (t == best and
+// id < best_id)), so any conservative traversal order returns the same
+// primitive as testing every primitive in ID order (the shader's strict '<',
+// compute.comp:239,260,301, makes the first primitive tested win a tie).
+#pragma once
+#include "device_math.h"
+#include "crt/types.h"
+
+namespace crt {
+
+struct DeviceScene {
+    const float4 *nodes;        // pair p = nodes[4p .. 4p+3] = {lo0|link0, hi0|count0, lo1|link1, hi1|count1}
+    uint32_t n_pairs;           // 0 = empty scene
+    const float4 *tri_pack;     // sorted slot s: {v0.xyz, e10.x} {e10.y, e10.z, e20.x, e20.y} {e20.z, id bits, -, -}
+    const float4 *sphere_pack;  // sorted slot s: {center.xyz, radius}
+    const float4 *quad_pack;    // sorted slot s: {normal.xyz, d} {corner.xyz, u.x} {u.y, u.z, v.x, v.y} {v.z, w.xyz}
+    const uint32_t *sphere_ids; // sorted slot -> input index
+    const uint32_t *quad_ids;
+    const crt_sphere *spheres;  // as uploaded (input order): shading data
+    const crt_quad *quads;
+    const crt_tri *tris;
+    const crt_material *materials;
+    const uint8_t *tex0;        // textures[0], RGBA8 rows top-down (the shader only ever samples index 0, compute.comp:387)
+    uint32_t tex0_w, tex0_h;
+    uint32_t n_textures;
+};
+
+constexpr int kLdsStack = 24;     // per-lane LDS stack entries; deeper levels spill to scratch
+constexpr int kSpillStack = 56;
+constexpr uint32_t kIdMiss = 0xFFFFFFFFu;
+
+CRT_DEV bool accept_hit(float t, uint32_t id, float best_t, uint32_t best_id) {
+    if (!(kTNear < t)) return false;
+    if (t < best_t) return true;
+    return t == best_t && id < best_id;
+}
+
+// compute.comp:229-239 (distance only)
+CRT_DEV bool sphere_t(V3 o, V3 d, float4 cr, float &t) {
+    V3 c = mk3(cr.x, cr.y, cr.z);
+    V3 rel = o - c;
+    float b = dot3(rel, d);
+    V3 qc = rel - b * d;
+    float disc = cr.w * cr.w - dot3(qc, qc);
+    if (disc < 0.0f) return false;
+    t = -b - __builtin_sqrtf(disc);
+    return true;
+}
+
+// compute.comp:253-268 (distance only)
+CRT_DEV bool quad_t(V3 o, V3 d, const float4 *q, float &t, float &alpha, float &beta) {
+    float4 a = q[0], b = q[1], c = q[2], e = q[3];
+    V3 n = mk3(a.x, a.y, a.z);
+    float denom = dot3(n, d);
+    if (__builtin_fabsf(denom) < 1e-8f) return false;
+    t = (a.w - dot3(n, o)) / denom;
+    V3 isect = o + t * d;
+    V3 planar = isect - mk3(b.x, b.y, b.z);
+    V3 u = mk3(b.w, c.x, c.y), v = mk3(c.z, c.w, e.x), w = mk3(e.y, e.z, e.w);
+    alpha = dot3(w, cross3(planar, v));
+    beta = dot3(w, cross3(u, planar));
+    if (!(alpha >= 0.0f && alpha <= 1.0f) || !(beta >= 0.0f && beta <= 1.0f)) return false;
+    return true;
+}
+
+// compute.comp:280-301 (distance only)
+CRT_DEV bool tri_t(V3 o, V3 d, V3 v0, V3 e10, V3 e20, float &t, float &beta, float &gamma, float &invDet) {
+    V3 p = cross3(d, e20);
+    float det = dot3(e10, p);
+    if (__builtin_fabsf(det) < 1e-8f) return false;
+    V3 r0 = o - v0;
+    V3 q = cross3(r0, e10);
+    beta = dot3(r0, p);
+    gamma = dot3(d, q);
+    if (beta < 0.0f || gamma < 0.0f || (beta + gamma) > det) return false;
+    invDet = 1.0f / det;
+    t = dot3(e20, q) * invDet;
+    return true;
+}
+
+struct Counts { uint32_t nodes, prims; };
+
+// Slab test for culling only (R5).  fma form: t = b * (1/d) - o * (1/d).  Boxes are padded at build
+// time and the far bound carries a relative pad, so rounding here never culls a primitive that an
+// exhaustive test would accept.
+CRT_DEV bool slab(float4 lo, float4 hi, V3 idir, V3 noid, float tfar, float &tn) {
+    float ax = __builtin_fmaf(lo.x, idir.x, noid.x), bx = __builtin_fmaf(hi.x, idir.x, noid.x);
+    float ay = __builtin_fmaf(lo.y, idir.y, noid.y), by = __builtin_fmaf(hi.y, idir.y, noid.y);
+    float az = __builtin_fmaf(lo.z, idir.z, noid.z), bz = __builtin_fmaf(hi.z, idir.z, noid.z);
+    float n0 = __builtin_fminf(ax, bx), f0 = __builtin_fmaxf(ax, bx);
+    float n1 = __builtin_fminf(ay, by), f1 = __builtin_fmaxf(ay, by);
+    float n2 = __builtin_fminf(az, bz), f2 = __builtin_fmaxf(az, bz);
+    tn = __builtin_fmaxf(__builtin_fmaxf(n0, n1), __builtin_fmaxf(n2, 0.0f));
+    float tf = __builtin_fminf(__builtin_fminf(f0, f1), __builtin_fminf(f2, tfar));
+    return tn <= tf;
+}
+
+template <bool COUNT>
+CRT_DEV void test_leaf(const DeviceScene &sc, V3 o, V3 d, uint32_t first, uint32_t count_kind, float &best_t, uint32_t &best_id, Counts &cnt) {
+    uint32_t kind = count_kind >> 28, n = count_kind & 0x0FFFFFFFu;
+    if (COUNT) cnt.prims += n;
+    if (kind == CRT_ID_KIND_TRI) {
+        for (uint32_t i = 0; i < n; i++) {
+            const float4 *p = sc.tri_pack + 3 * (size_t)(first + i);
+            float4 a = p[0], b = p[1], c = p[2];
+            float t, beta, gamma, invDet;
+            if (tri_t(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, beta, gamma, invDet)) {
+                uint32_t id = f2u(c.y);
+                if (accept_hit(t, id, best_t, best_id)) { best_t = t; best_id = id; }
+            }
+        }
+    } else if (kind == CRT_ID_KIND_SPHERE) {
+        for (uint32_t i = 0; i < n; i++) {
+            float t;
+            if (sphere_t(o, d, sc.sphere_pack[first + i], t) && kTNear < t && t <= best_t) {
+                uint32_t id = CRT_MAKE_ID(CRT_ID_KIND_SPHERE, sc.sphere_ids[first + i]);
+                if (accept_hit(t, id, best_t, best_id)) { best_t = t; best_id = id; }
+            }
+        }
+    } else {
+        for (uint32_t i = 0; i < n; i++) {
+            float t, alpha, beta;
+            if (quad_t(o, d, sc.quad_pack + 4 * (size_t)(first + i), t, alpha, beta) && kTNear < t && t <= best_t) {
+                uint32_t id = CRT_MAKE_ID(CRT_ID_KIND_QUAD, sc.quad_ids[first + i]);
+                if (accept_hit(t, id, best_t, best_id)) { best_t = t; best_id = id; }
+            }
+        }
+    }
+}
+
+// R6: closest hit.  `stack` points at this lane's column of the block's LDS stack (stride = blockDim).
+template <bool COUNT>
+CRT_DEV void closest_hit(const DeviceScene &sc, V3 o, V3 d, uint32_t *stack, uint32_t stack_stride,
+                         float &best_t, uint32_t &best_id, Counts &cnt) {
+    best_t = kInf; best_id = kIdMiss;
+    if (sc.n_pairs == 0) return;
+    V3 idir;
+    idir.x = __builtin_fabsf(d.x) > 1e-30f ? 1.0f / d.x : __builtin_copysignf(1e30f, d.x);
+    idir.y = __builtin_fabsf(d.y) > 1e-30f ? 1.0f / d.y : __builtin_copysignf(1e30f, d.y);
+    idir.z = __builtin_fabsf(d.z) > 1e-30f ? 1.0f / d.z : __builtin_copysignf(1e30f, d.z);
+    V3 noid = mk3(-(o.x * idir.x), -(o.y * idir.y), -(o.z * idir.z));
+    uint32_t spill[kSpillStack];
+    int sp = 0;
+    uint32_t cur = 0;
+    float tfar = kInf;
+    for (;;) {
+        const float4 *p = sc.nodes + 4 * (size_t)cur;
+        float4 lo0 = p[0], hi0 = p[1], lo1 = p[2], hi1 = p[3];
+        if (COUNT) cnt.nodes += 2;
+        float tn0, tn1;
+        bool h0 = slab(lo0, hi0, idir, noid, tfar, tn0);
+        bool h1 = slab(lo1, hi1, idir, noid, tfar, tn1);
+        uint32_t c0 = f2u(hi0.w), c1 = f2u(hi1.w);
+        if (h0 && c0 != 0) { test_leaf<COUNT>(sc, o, d, f2u(lo0.w), c0, best_t, best_id, cnt); h0 = false; }
+        if (h1 && c1 != 0) { test_leaf<COUNT>(sc, o, d, f2u(lo1.w), c1, best_t, best_id, cnt); h1 = false; }
+        tfar = best_t * 1.000004f;       // relative pad (2^-18) on the far bound
+        uint32_t l0 = f2u(lo0.w), l1 = f2u(lo1.w);
+        if (h0 && h1) {
+            bool first0 = tn0 <= tn1;
+            uint32_t nearc = first0 ? l0 : l1, farc = first0 ? l1 : l0;
+            if (sp < kLdsStack) stack[sp * stack_stride] = farc; else if (sp < kLdsStack + kSpillStack) spill[sp - kLdsStack] = farc;
+            sp++;
+            cur = nearc;
+        } else if (h0) cur = l0;
+        else if (h1) cur = l1;
+        else {
+            if (sp == 0) break;
+            sp--;
+            cur = sp < kLdsStack ? stack[sp * stack_stride] : spill[sp - kLdsStack];
+        }
+    }
+}
+
+// The shader's HitRecord (compute.comp:195-203), rebuilt for the winning primitive from the
+// uploaded arrays with the same arithmetic hit_sphere/hit_quad/hit_tri use at the moment of the hit.
+// (In hit_tri the invDet/beta/gamma are functions of the ray and the triangle only, so evaluating
+// them again after traversal gives the same bits.)
+struct HitRecord {
+    V3 position, normal;
+    float u, v;
+    bool front;
+    uint32_t materialIndex;
+};
+
+// compute.comp:207-210
+CRT_DEV void set_face_normal(V3 d, V3 outward, HitRecord &rec) {
+    rec.front = dot3(d, outward) < 0.0f;
+    rec.normal = rec.front ? outward : neg3(outward);
+}
+
+CRT_DEV void sphere_uv(V3 outward, float &u, float &v) {   // compute.comp:247-250
+    float theta = dm_acos(-outward.y);
+    float phi = dm_atan2(-outward.z, outward.x) + kPi;
+    u = phi / (2.0f * kPi);
+    v = theta / kPi;
+}
+
+// Position, face normal and material of the winning primitive.
+CRT_DEV void resolve_hit(const DeviceScene &sc, V3 o, V3 d, float t, uint32_t id, HitRecord &rec) {
+    uint32_t kind = id >> 30, idx = id & 0x3FFFFFFFu;
+    rec.u = 0.0f; rec.v = 0.0f;
+    rec.position = o + t * d;
+    if (kind == CRT_ID_KIND_TRI) {                       // compute.comp:303-307
+        const float4 *p = (const float4 *)(sc.tris + idx);
+        float4 a = p[0], b = p[1], c = p[2];
+        V3 v0 = mk3(a.x, a.y, a.z);
+        V3 e10 = mk3(b.x, b.y, b.z) - v0, e20 = mk3(c.x, c.y, c.z) - v0;
+        set_face_normal(d, cross3(e20, e10), rec);       // not normalised (sic)
+        rec.materialIndex = sc.tris[idx].materialIndex;
+    } else if (kind == CRT_ID_KIND_SPHERE) {             // compute.comp:241-245
+        float4 cr = *(const float4 *)(sc.spheres + idx);
+        V3 outward = (rec.position - mk3(cr.x, cr.y, cr.z)) / cr.w;
+        set_face_normal(d, outward, rec);
+        rec.materialIndex = sc.spheres[idx].materialIndex;
+    } else {                                             // compute.comp:270-273
+        const crt_quad &q = sc.quads[idx];
+        set_face_normal(d, ld3(q.normal), rec);
+        rec.materialIndex = q.materialIndex;
+    }
+}
+
+// Texture coordinates of the hit; only evaluated for a textured material (the values are the ones the
+// shader computes at every hit and then ignores for untextured materials).
+CRT_DEV void resolve_uv(const DeviceScene &sc, V3 o, V3 d, uint32_t id, HitRecord &rec) {
+    uint32_t kind = id >> 30, idx = id & 0x3FFFFFFFu;
+    if (kind == CRT_ID_KIND_TRI) {                       // compute.comp:309-314
+        const float4 *p = (const float4 *)(sc.tris + idx);
+        float4 a = p[0], b = p[1], c = p[2], tu = p[3], tv = p[4];
+        V3 v0 = mk3(a.x, a.y, a.z);
+        V3 e10 = mk3(b.x, b.y, b.z) - v0, e20 = mk3(c.x, c.y, c.z) - v0;
+        float tt, beta, gamma, invDet;
+        tri_t(o, d, v0, e10, e20, tt, beta, gamma, invDet);
+        beta = beta * invDet; gamma = gamma * invDet;
+        float alpha = 1.0f - beta - gamma;
+        rec.u = (alpha * tu.x + beta * tu.y) + gamma * tu.z;
+        rec.v = (alpha * tv.x + beta * tv.y) + gamma * tv.z;
+    } else if (kind == CRT_ID_KIND_SPHERE) {             // compute.comp:247-250
+        float4 cr = *(const float4 *)(sc.spheres + idx);
+        V3 outward = (rec.position - mk3(cr.x, cr.y, cr.z)) / cr.w;
+        sphere_uv(outward, rec.u, rec.v);
+    } else {                                             // compute.comp:264-266,274-275
+        const crt_quad &q = sc.quads[idx];
+        V3 planar = rec.position - ld3(q.corner);
+        rec.u = dot3(ld3(q.w), cross3(planar, ld3(q.v)));
+        rec.v = dot3(ld3(q.w), cross3(ld3(q.u), planar));
+    }
+}
+
+}  // namespace crt

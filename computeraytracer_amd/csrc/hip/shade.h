@@ -1,0 +1,116 @@
+// shade.h -- camera ray generation, materials, sky, texture fetch
+// (R4, R10-R13 and T8 of SURVEY.md section 8(a)).
+#pragma once
+#include "intersect.h"
+
+namespace crt {
+
+// compute.comp:163-172
+template <int M>
+CRT_DEV void camera_get_ray(const crt_camera_data &cam, float u, float v, Rng<M> &rng, V3 &origin, V3 &dir) {
+    float dx, dy; random_in_unit_disk(rng, dx, dy);
+    float rx = cam.lensRadius * dx, ry = cam.lensRadius * dy;
+    V3 offset = ld3(cam.right) * rx + ld3(cam.up) * ry;
+    V3 pos = ld3(cam.position), H = ld3(cam.horizontal), Vv = ld3(cam.vertical);
+    V3 llc = ((pos - H * 0.5f) - Vv * 0.5f) - cam.focusDistance * ld3(cam.backward);
+    origin = pos + offset;
+    dir = normalize3(((llc + u * H) + v * Vv) - origin);
+}
+
+// RGBA8 UNORM, bilinear, REPEAT, texel centres at +0.5 (vk_initializers.cpp:252-261); plain float weights.
+CRT_DEV V3 texel(const uint8_t *tex, uint32_t w, int x, int y) {
+    uint32_t p = *(const uint32_t *)(tex + 4 * ((size_t)y * w + (size_t)x));
+    return mk3((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f);
+}
+CRT_DEV int wrapi(float f, int n) { int i = (int)f % n; return i < 0 ? i + n : i; }
+CRT_DEV V3 sample_texture(const uint8_t *tex, uint32_t w, uint32_t h, float u, float v) {
+    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    float x0f = __builtin_floorf(x), y0f = __builtin_floorf(y);
+    float fx = x - x0f, fy = y - y0f;
+    int x0 = wrapi(x0f, (int)w), y0 = wrapi(y0f, (int)h);
+    int x1 = x0 + 1 == (int)w ? 0 : x0 + 1, y1 = y0 + 1 == (int)h ? 0 : y0 + 1;
+    V3 t00 = texel(tex, w, x0, y0), t10 = texel(tex, w, x1, y0), t01 = texel(tex, w, x0, y1), t11 = texel(tex, w, x1, y1);
+    V3 top = t00 * (1.0f - fx) + t10 * fx;
+    V3 bot = t01 * (1.0f - fx) + t11 * fx;
+    return top * (1.0f - fy) + bot * fy;
+}
+
+CRT_DEV V3 reflect3(V3 I, V3 N) { return I - (2.0f * dot3(N, I)) * N; }           // GLSL reflect
+CRT_DEV V3 refract3(V3 I, V3 N, float eta) {                                     // GLSL refract
+    float ni = dot3(N, I);
+    float k = 1.0f - eta * eta * (1.0f - ni * ni);
+    if (k < 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+    return eta * I - (eta * ni + __builtin_sqrtf(k)) * N;
+}
+
+// compute.comp:176-191
+template <int M>
+CRT_DEV bool should_refract(V3 incoming, V3 normal, float ior, float ratio, Rng<M> &rng) {
+    float cosTheta = __builtin_fminf(dot3(neg3(incoming), normal), 1.0f);
+    float sinTheta = __builtin_sqrtf(1.0f - cosTheta * cosTheta);
+    if (ratio * sinTheta > 0.999f) return false;
+    float reflectance = (1.0f - ior) / (1.0f + ior);
+    reflectance = reflectance * reflectance;
+    float schlick = reflectance + (1.0f - reflectance) * dm_pow5(1.0f - cosTheta);
+    if (schlick > hash_1(rng)) return false;
+    return true;
+}
+
+// One bounce of ray_color's loop body after a hit (compute.comp:451-455): emit + scatter + throughput
+// update.  Returns false when the path ends here; `result` then holds its radiance.
+template <int M>
+CRT_DEV bool shade_hit(const DeviceScene &sc, V3 &o, V3 &d, float t, uint32_t id, Rng<M> &rng,
+                       V3 &color, V3 &emitted, V3 &result) {
+    HitRecord rec;
+    resolve_hit(sc, o, d, t, id, rec);
+    const float4 *mp = (const float4 *)(sc.materials + rec.materialIndex);
+    float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
+    V3 albedo = mk3(m0.x, m0.y, m0.z);
+    float fuzz = m0.w;
+    uint32_t type = f2u(m1.w), texIndex = f2u(m2.w);
+    // emit(), :363-371
+    V3 e = type == CRT_MAT_DIFFUSE_LIGHT ? albedo : mk3(0.0f, 0.0f, 0.0f);
+    emitted = emitted + color * e;
+    // scatter(), :373-419
+    V3 attenuation = albedo;
+    if (type == CRT_MAT_LAMBERTIAN) {
+        V3 dir = rec.normal + random_in_unit_sphere(rng);
+        if (texIndex != CRT_BAD_INDEX && sc.n_textures > 0) {
+            resolve_uv(sc, o, d, id, rec);
+            attenuation = sample_texture(sc.tex0, sc.tex0_w, sc.tex0_h, rec.u, rec.v);   // always textures[0] (sic, :387)
+        }
+        o = rec.position; d = normalize3(dir);
+    } else if (type == CRT_MAT_METAL) {
+        V3 refl = reflect3(d, rec.normal);
+        refl = refl + fuzz * random_in_unit_sphere(rng);
+        o = rec.position; d = normalize3(refl);
+        if (!(dot3(d, rec.normal) > 0.0f)) { result = emitted; return false; }
+    } else if (type == CRT_MAT_DIELECTRIC) {
+        float ratio = rec.front ? 1.0f / fuzz : fuzz;
+        V3 dir = should_refract(d, rec.normal, fuzz, ratio, rng) ? refract3(d, rec.normal, ratio) : reflect3(d, rec.normal);
+        o = rec.position; d = normalize3(dir);
+        attenuation = mk3(1.0f, 1.0f, 1.0f);
+    } else {
+        result = emitted;
+        return false;
+    }
+    color = color * (attenuation + emitted);      // sic, :455
+    return true;
+}
+
+// compute.comp:443-449
+CRT_DEV V3 shade_miss(const crt_scene_params &p, V3 d, V3 color) {
+    if (p.backgroundColor[0] != -1.0f || p.backgroundColor[1] != -1.0f || p.backgroundColor[2] != -1.0f)
+        return ld3(p.backgroundColor);
+    float a = 0.5f * (d.y + 1.0f);
+    V3 sky = mk3(1.0f, 1.0f, 1.0f) * (1.0f - a) + mk3(0.5f, 0.7f, 1.0f) * a;
+    return color * sky;
+}
+
+// compute.comp:474: cum += int(iteration == 1) * -cum + pass
+CRT_DEV V3 accumulate(V3 cum, V3 pass, float iteration) {
+    float first = (float)(int)(iteration == 1.0f);
+    return cum + ((first * neg3(cum)) + pass);
+}
+
+}  // namespace crt

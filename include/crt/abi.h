@@ -1,0 +1,179 @@
+/*
+ * crt/abi.h -- the drop-in boundary of the MI355X ray-tracing core.
+ *
+ * The reference has no plugin/FFI interface; its boundary is the Vulkan
+ * descriptor + dispatch surface inside VulkanEngine (engine/src/vk_engine.cpp).
+ * Each entry point below replaces one piece of that surface and says which.
+ * Plain C ABI: pointers and sizes only, no C++ or torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative crt_status otherwise;
+ *     crt_last_error(ctx) returns a message owned by ctx.  Nothing aborts
+ *     (the reference abort()s: vk_engine.cpp:27-34,86-95).
+ *   - host buffers are copied synchronously; the caller keeps ownership and
+ *     may free them as soon as the call returns (as upload_buffer's staging
+ *     copy + fence wait does: vk_engine.cpp:656-690,1293-1315).
+ *   - a context is bound to one GPU and is used by one thread at a time.
+ *     crt_dispatch/crt_render enqueue on the context's HIP stream and return;
+ *     crt_sync and every *_read call block until the work is done.
+ *   - the library never falls back to the CPU: without a usable HIP device
+ *     crt_create fails.
+ */
+#ifndef CRT_ABI_H
+#define CRT_ABI_H
+
+#include <stddef.h>
+#include "crt/types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct crt_context crt_context;
+
+enum crt_status {
+    CRT_OK = 0,
+    CRT_ERR_INVALID = -1,     /* bad argument / call order */
+    CRT_ERR_HIP = -2,         /* a HIP runtime call failed */
+    CRT_ERR_NO_DEVICE = -3,   /* no usable GPU */
+    CRT_ERR_IO = -4           /* file could not be read / parsed */
+};
+
+/* Library version string, e.g. "crt-mi355x 0.1 (gfx950)". */
+const char *crt_version(void);
+
+/* Replaces init_vulkan + allocator set-up (vk_engine.cpp:110-212): binds a
+ * context to HIP device `device`, creates its stream. */
+int crt_create(int device, crt_context **out);
+void crt_destroy(crt_context *ctx);
+const char *crt_last_error(const crt_context *ctx);
+
+/* Replaces creation of the RGBA32F storage image (vk_engine.cpp:1157-1168) and
+ * the compile-time knobs of the shader (compute.comp:15-16,21).  Allocates the
+ * zero-initialised accumulation image; may be called again to resize/reset. */
+int crt_configure(crt_context *ctx, const crt_config *cfg);
+
+/* Replaces the five upload_buffer calls + texture descriptors of
+ * init_descriptors (vk_engine.cpp:1177-1229).  Invalidates any BVH. */
+int crt_scene_upload(crt_context *ctx, const crt_scene_desc *scene);
+
+/* Replaces BVHNode::BVHNode + gpu_serialize on the host
+ * (raytracing/src/bounding_volume_hierarchy.cpp:63-130) with a device-side
+ * build over the uploaded primitives.  flags: CRT_BVH_*.  build_ms (optional)
+ * receives the device time of the build. */
+int crt_bvh_build(crt_context *ctx, uint32_t flags, float *build_ms);
+
+/* Config 5 (per-frame rebuild): overwrite the triangle vertices in place from
+ * device-resident or host memory, then call crt_bvh_build again.  No
+ * counterpart in the reference (its BVHs are built once: vk_engine.cpp:748-934). */
+int crt_tris_update(crt_context *ctx, const crt_tri *tris, uint32_t first, uint32_t count);
+/* Device-side animation used by the 10M-triangle benchmark: displaces every
+ * triangle vertex's y by amplitude * sin(frame + x + z) relative to the
+ * uploaded rest pose. */
+int crt_tris_animate(crt_context *ctx, float frame, float amplitude);
+
+/* Replaces one frame of VulkanEngine::draw (vk_engine.cpp:1409-1435): the
+ * 112-byte UBO write + vkCmdDispatch(W/8, H/8, 1).  One sample per pixel;
+ * params->camera.iteration == 1 resets the accumulation (compute.comp:474). */
+int crt_dispatch(crt_context *ctx, const crt_scene_params *params);
+
+/* n dispatches enqueued back to back: dispatch i uses *params with
+ * camera.iteration = first_iteration + i and camera.seed = seeds[i].
+ * Equivalent to n crt_dispatch calls (bit-identical image). */
+int crt_render(crt_context *ctx, const crt_scene_params *params, uint32_t first_iteration,
+               uint32_t n_iterations, const float *seeds);
+
+/* Replaces waitForFences(renderFence) (vk_engine.cpp:1377). */
+int crt_sync(crt_context *ctx);
+
+/* Replaces the present pass's read of the storage image (vk_engine.cpp:1448-1458):
+ * copies the raw accumulation image (RGBA32F, xyz = running sum, w = iteration,
+ * row 0 = bottom of the view) into rgba (width*height*4 floats). */
+int crt_image_read(crt_context *ctx, float *rgba, size_t n_floats);
+
+/* Build-only diagnostic: primary-hit primitive ID per pixel of the most
+ * recent dispatch (CRT_ID_MISS where the camera ray hit nothing or the pixel
+ * is outside the rendered grid). */
+int crt_hit_ids_read(crt_context *ctx, uint32_t *ids, size_t n_ids);
+
+/* Device pointer + size of this context's packed band buffer (the rows it
+ * owns, in increasing y, each row width*4 floats) for a device-to-device
+ * gather (RCCL all-gather over xGMI in the multi-GPU harness).  With
+ * band_world <= 1 this is the whole image. */
+int crt_image_device_ptr(crt_context *ctx, void **device_ptr, size_t *n_bytes);
+/* Rows owned by (band_rank, band_world) for a given height: writes the y of
+ * each owned row in increasing order; returns the count (rows may be NULL). */
+uint32_t crt_band_rows(uint32_t height, uint32_t band_rank, uint32_t band_world, uint32_t *rows);
+
+/* Counters since the last crt_stats_reset (rays = hit_world calls). */
+int crt_stats_read(crt_context *ctx, crt_stats *out);
+int crt_stats_reset(crt_context *ctx);
+/* Makes the next dispatches count node visits and primitive tests too
+ * (slower; used to measure the V and T terms of the bytes-per-ray model). */
+int crt_set_instrumented(crt_context *ctx, int on);
+
+/* Read back the build's BVH for cross-checks: nodes (pair layout, see
+ * crt_bvh_node) and, per kind, the input ID of each sorted primitive slot.
+ * Two-call protocol: pass NULL arrays to get the counts. */
+int crt_bvh_read(crt_context *ctx, crt_bvh_node *nodes, uint32_t *n_nodes,
+                 uint32_t *sphere_ids, uint32_t *quad_ids, uint32_t *tri_ids);
+
+/* ---- host-side helpers (no GPU needed) --------------------------------- */
+
+/* Camera::Camera + Camera::calculateProperties (raytracing/src/camera.cpp:3-12,40-62):
+ * fills the 96-byte camera block; iteration = 1, seed = 0. */
+void crt_camera_init(crt_camera_data *out, const float position[3], const float at[3],
+                     float fov_degrees, float aspect_ratio, float aperture, float focus_distance);
+
+/* Frame-seed schedule of vk_engine.cpp:1412: seeds[i] = float(r_i) / 1E3f with
+ * r_i the i-th output of glibc rand() seeded 1 (restated, libc-independent). */
+void crt_frame_seeds(uint32_t first, uint32_t count, float *seeds);
+
+/* Quad::Quad derived fields (primitives.h:73-80): fills normal, d, w from
+ * corner/u/v. */
+void crt_quad_init(crt_quad *q, const float corner[3], const float u[3], const float v[3], uint32_t material);
+
+/* Built-in scenes: the reference's four (vk_engine.cpp:825-926: "book1",
+ * "quads", "corne", "cirno") and the benchmark ones ("monkey", "voxel_city",
+ * "grid10m").  mesh/texture inputs come from files under asset_dir where a
+ * scene needs them.  The returned scene owns its arrays until crt_scene_free. */
+typedef struct crt_host_scene crt_host_scene;
+int crt_scene_builtin(const char *name, const char *asset_dir, uint32_t width, uint32_t height, crt_host_scene **out);
+const crt_scene_desc *crt_host_scene_desc(const crt_host_scene *s);
+const crt_scene_params *crt_host_scene_params(const crt_host_scene *s);
+/* The world list handed to the reference's BVHNode ctor, as CSR over input
+ * IDs, for the oracle's reference-BVH mode. */
+int crt_host_scene_world(const crt_host_scene *s, uint32_t *n_objects, const uint32_t **obj_offsets,
+                         const uint32_t **obj_prims, const uint8_t **obj_is_list);
+void crt_scene_free(crt_host_scene *s);
+const char *crt_host_last_error(void);
+
+/* OBJ -> triangle soup with the asset baker's conventions
+ * (asset-baker/asset_main.cpp:38-100: de-indexed, uv.y = 1 - uy, shapes merged).
+ * *tris is malloc'ed; free with crt_free. */
+int crt_load_obj(const char *path, uint32_t material_index, crt_tri **tris, uint32_t *n_tris);
+void crt_free(void *p);
+
+/* The reference's asset container (asset-lib/src/asset_loader.cpp:13-61): 16-byte
+ * header {type[4], u32 version, u32 jsonLen, u32 blobLen} + JSON + LZ4 block.
+ * "MESH" (mesh_asset.cpp:15-112): blob = LZ4(PNCV_F32 vertices || u32 indices).
+ * "TEXI" (texture_asset.cpp:12-70): blob = LZ4(RGBA8 rows, top-down).
+ * Outputs are malloc'ed; free with crt_free. */
+int crt_mesh_file_read(const char *path, float **vertices_pncv, uint32_t *n_vertices, uint32_t **indices, uint32_t *n_indices);
+int crt_mesh_file_write(const char *path, const float *vertices_pncv, uint32_t n_vertices, const uint32_t *indices,
+                        uint32_t n_indices, const char *original_file);
+int crt_texture_file_read(const char *path, uint8_t **rgba8, uint32_t *width, uint32_t *height);
+int crt_texture_file_write(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height, const char *original_file);
+/* OBJ -> PNCV vertex list exactly as the baker's extract_mesh_from_obj emits it
+ * (asset_main.cpp:67-100): one vertex per face corner, indices 0..n-1. */
+int crt_obj_to_vertices(const char *path, float **vertices_pncv, uint32_t *n_vertices);
+/* In-tree LZ4 block codec (format of lz4 >= 1.9.4's LZ4_compress_default /
+ * LZ4_decompress_safe).  Return the output size or a negative crt_status. */
+int crt_lz4_compress_bound(int n);
+int crt_lz4_compress(const uint8_t *src, int n, uint8_t *dst, int cap);
+int crt_lz4_decompress(const uint8_t *src, int n, uint8_t *dst, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRT_ABI_H */

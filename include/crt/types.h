@@ -1,0 +1,183 @@
+/*
+ * crt/types.h -- POD layouts at the drop-in boundary.
+ *
+ * Every struct here is byte-identical to the buffer element the reference
+ * engine uploads to (or reads back from) its Vulkan compute pipeline, so a
+ * caller that already fills the reference's SSBO/UBO staging memory can hand
+ * the same bytes to crt_scene_upload()/crt_dispatch().  File:line citations
+ * are relative to the upstream ComputeRaytracer checkout.
+ */
+#ifndef CRT_TYPES_H
+#define CRT_TYPES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRT_BAD_INDEX 0xFFFFFFFFu
+
+/* Hittable::Type, raytracing/include/hittable.h:13-18; shaders/compute.comp:11-13 */
+enum { CRT_TYPE_SPHERE = 1, CRT_TYPE_QUAD = 2, CRT_TYPE_TRI = 4, CRT_TYPE_BVH_NODE = 8 };
+
+/* RTMaterial::Type, raytracing/include/rt_material.h:13-18; compute.comp:6-9 */
+enum { CRT_MAT_LAMBERTIAN = 1, CRT_MAT_METAL = 2, CRT_MAT_DIELECTRIC = 4, CRT_MAT_DIFFUSE_LIGHT = 8 };
+
+/* Sphere::GPU_t, raytracing/include/primitives.h:29-34; compute.comp:34-39 (32 B) */
+typedef struct crt_sphere {
+    float center[3];
+    float radius;            /* may be negative: flips the outward normal */
+    float pad0[3];
+    uint32_t materialIndex;
+} crt_sphere;
+
+/* Quad::GPU_t, primitives.h:62-70; compute.comp:41-49 (96 B) */
+typedef struct crt_quad {
+    float corner[3]; float d;      /* d = dot(normal, corner) */
+    float u[3];      float pad0;
+    float v[3];      float pad1;
+    float normal[3]; float pad2;   /* normalize(cross(u, v)) */
+    float w[3];      float pad3;   /* n / dot(n, n), n = cross(u, v) */
+    float pad4[3];
+    uint32_t materialIndex;
+} crt_quad;
+
+/* Tri::GPU_t, primitives.h:123-131; compute.comp:51-59 (96 B) */
+typedef struct crt_tri {
+    float v0[3]; float pad0;
+    float v1[3]; float pad1;
+    float v2[3]; float pad2;
+    float u[3];  float pad3;       /* texture u at v0, v1, v2 */
+    float v[3];  float pad4;       /* texture v at v0, v1, v2 */
+    float pad5[3];
+    uint32_t materialIndex;
+} crt_tri;
+
+/* RTMaterial::GPU_t, rt_material.h:20-31; compute.comp:25-32 (48 B) */
+typedef struct crt_material {
+    float albedo[3];
+    float fuzziness;         /* metal fuzz, or index of refraction for a dielectric */
+    float pad0[3];
+    uint32_t type;
+    float pad1[3];
+    uint32_t textureIndex;   /* CRT_BAD_INDEX = untextured */
+} crt_material;
+
+/* BVHNode::GPU_t, bounding_volume_hierarchy.h:15-24; compute.comp:61-76 (64 B).
+ * Only used when a caller supplies the reference's own threaded BVH for A/B runs. */
+typedef struct crt_ref_bvh_node {
+    float aabb_min[3]; float pad1;
+    float aabb_max[3]; float pad2;
+    uint32_t objectIndex;    /* CRT_BAD_INDEX on an inner node */
+    uint32_t hitIndex;
+    uint32_t missIndex;
+    float pad3;
+    uint32_t type;
+    uint32_t numChildren;    /* 0 on an inner node */
+    float pad4[2];
+} crt_ref_bvh_node;
+
+/* GPUCameraData, raytracing/include/camera.h:9-22; compute.comp:78-91 (96 B) */
+typedef struct crt_camera_data {
+    float position[3];   uint32_t shouldRenderAABB;
+    float backward[3];   float lensRadius;
+    float right[3];      float focusDistance;
+    float up[3];         float iteration;      /* 1-based frame counter, as float */
+    float horizontal[3]; float seed;           /* float(rand()) / 1E3f, vk_engine.cpp:1412 */
+    float vertical[3];   float pad;
+} crt_camera_data;
+
+/* GPUSceneData, raytracing/include/scene.h:13-17; compute.comp:93-97 (112 B) */
+typedef struct crt_scene_params {
+    float backgroundColor[3];   /* (-1,-1,-1) = default sky gradient */
+    float pad;
+    crt_camera_data camera;
+} crt_scene_params;
+
+/* One RGBA8 UNORM texture, rows top-down, 1 mip (vk_engine.cpp:597-605). */
+typedef struct crt_texture {
+    const uint8_t *rgba8;
+    uint32_t width;
+    uint32_t height;
+} crt_texture;
+
+/* What init_descriptors binds once per scene (vk_engine.cpp:1177-1229): host
+ * pointers to the six arrays.  Zero-length arrays may be NULL. */
+typedef struct crt_scene_desc {
+    const crt_sphere   *spheres;    uint32_t n_spheres;
+    const crt_quad     *quads;      uint32_t n_quads;
+    const crt_tri      *tris;       uint32_t n_tris;
+    const crt_material *materials;  uint32_t n_materials;
+    const crt_texture  *textures;   uint32_t n_textures;
+} crt_scene_desc;
+
+/*
+ * Primitive IDs.  A primitive's ID is its position in the array it was
+ * uploaded in, tagged with its kind: (kind << 30) | index, kind 0 = sphere,
+ * 1 = quad, 2 = tri.  CRT_ID_MISS marks "no hit".  IDs do not depend on how the
+ * BVH was built.  On exactly equal hit distances the lowest ID wins.
+ */
+#define CRT_ID_KIND_SPHERE 0u
+#define CRT_ID_KIND_QUAD   1u
+#define CRT_ID_KIND_TRI    2u
+#define CRT_ID_MISS        0xFFFFFFFFu
+#define CRT_MAKE_ID(kind, index) (((uint32_t)(kind) << 30) | (uint32_t)(index))
+
+/* crt_config.rng_mode */
+enum {
+    CRT_RNG_REF = 0,   /* the shader's float-seeded integer hash, compute.comp:116-139 (bit-exact) */
+    CRT_RNG_PCG = 1    /* pcg32 stream keyed by (pixel, iteration): well-behaved quality mode */
+};
+
+/* crt_config.tracer */
+enum {
+    CRT_TRACER_MEGAKERNEL = 0,  /* one lane per pixel for the whole path (the shader's shape) */
+    CRT_TRACER_WAVEFRONT  = 1   /* generate / extend / shade+compact queues */
+};
+
+/* crt_config.flags */
+enum {
+    CRT_FLAG_FULL_IMAGE = 1u << 0  /* render all W x H pixels; default renders floor(W/8)*8 x floor(H/8)*8
+                                      like dispatch(W/8, H/8, 1), vk_engine.cpp:1435 */
+};
+
+typedef struct crt_config {
+    uint32_t width, height;     /* accumulation image size (imageSize() in the shader) */
+    uint32_t rng_mode;
+    uint32_t tracer;
+    uint32_t flags;
+    uint32_t max_bounces;       /* 0 = the shader's MAX_BOUNCES (10), compute.comp:16 */
+    uint32_t band_rank;         /* this context renders the 8-row bands b with b % band_world == band_rank */
+    uint32_t band_world;        /* 0 or 1 = whole image */
+} crt_config;
+
+/* crt_bvh_build flags */
+enum {
+    CRT_BVH_LBVH       = 0,        /* Morton LBVH only (fast rebuild path) */
+    CRT_BVH_SAH_REFINE = 1u << 0   /* + binned-SAH refinement */
+};
+
+/* The build's own BVH node (32 B).  Nodes are stored as sibling pairs:
+ * pair p = nodes[2p], nodes[2p+1] (64 B, one half cache line).
+ *   inner: link = index of its child pair, count = 0
+ *   leaf:  link = first primitive slot in the kind's sorted array,
+ *          count = (kind << 28) | number of primitives (>= 1)                */
+typedef struct crt_bvh_node {
+    float lo[3]; uint32_t link;
+    float hi[3]; uint32_t count;
+} crt_bvh_node;
+
+typedef struct crt_stats {
+    uint64_t rays;            /* hit_world calls (primary + every bounce segment) since last reset */
+    uint64_t paths;           /* camera samples started */
+    uint64_t node_visits;     /* only counted by instrumented launches */
+    uint64_t prim_tests;      /* only counted by instrumented launches */
+    double   last_render_ms;  /* device time of the last crt_dispatch/crt_render */
+    double   last_build_ms;   /* device time of the last crt_bvh_build */
+} crt_stats;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRT_TYPES_H */

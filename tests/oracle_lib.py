@@ -1,0 +1,145 @@
+"""ctypes binding of oracle/_build/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() import
+this module; nothing under computeraytracer_amd/ does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+
+TRAVERSE_BRUTE, TRAVERSE_FAST, TRAVERSE_REF, TRAVERSE_BUILD = 0, 1, 2, 3
+RNG_PCG, FULL_IMAGE, LIBM = 1 << 4, 1 << 5, 1 << 6
+
+
+class OrcScene(C.Structure):
+    _fields_ = [("spheres", C.c_void_p), ("n_spheres", C.c_uint32), ("quads", C.c_void_p), ("n_quads", C.c_uint32),
+                ("tris", C.c_void_p), ("n_tris", C.c_uint32), ("materials", C.c_void_p), ("n_materials", C.c_uint32),
+                ("textures", C.c_void_p), ("n_textures", C.c_uint32)]
+
+
+class OrcTexture(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class OrcWorld(C.Structure):
+    _fields_ = [("n_objects", C.c_uint32), ("obj_offsets", C.c_void_p), ("obj_prims", C.c_void_p), ("obj_is_list", C.c_void_p)]
+
+
+class OrcBuildBvh(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_uint32), ("sphere_ids", C.c_void_p), ("quad_ids", C.c_void_p),
+                ("tri_ids", C.c_void_p)]
+
+
+class OrcCounters(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64), ("paths", C.c_uint64),
+                ("bounces", C.c_uint64)]
+
+
+def _load():
+    if not os.path.exists(LIB) and os.path.exists(os.path.join(ROOT, "oracle", "Makefile")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    lib = C.CDLL(LIB)
+    vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int, C.c_float
+    lib.orc_render.restype = i32
+    lib.orc_render.argtypes = [C.POINTER(OrcScene), C.POINTER(OrcWorld), C.POINTER(OrcBuildBvh), vp, u32, u32, u32, i32, i32, i32,
+                               vp, vp, C.POINTER(OrcCounters)]
+    lib.orc_ref_bvh.restype = i32
+    lib.orc_ref_bvh.argtypes = [C.POINTER(OrcScene), C.POINTER(OrcWorld), vp, C.POINTER(u32), vp, C.POINTER(u32), vp, C.POINTER(u32),
+                                vp, C.POINTER(u32)]
+    lib.orc_hash.argtypes = [C.POINTER(f32), i32, C.POINTER(f32)]
+    lib.orc_base_hash.restype = u32
+    lib.orc_base_hash.argtypes = [u32, u32]
+    lib.orc_pixel_seed.restype = f32
+    lib.orc_pixel_seed.argtypes = [f32, u32, u32]
+    lib.orc_pcg.argtypes = [u32, f32, f32, u32, vp]
+    lib.orc_math.argtypes = [i32, u32, vp, vp, vp, vp, i32]
+    lib.orc_hit_prim.restype = i32
+    lib.orc_hit_prim.argtypes = [i32, vp, vp, vp, f32, vp]
+    lib.orc_hit_aabb.restype = i32
+    lib.orc_hit_aabb.argtypes = [vp, vp, vp, vp, f32]
+    lib.orc_sample_texture.argtypes = [vp, u32, u32, f32, f32, vp]
+    lib.orc_camera_ray.argtypes = [vp, f32, f32, f32, vp]
+    lib.orc_camera.argtypes = [vp, vp, f32, f32, f32, f32, vp]
+    lib.orc_glibc_rand.argtypes = [u32, u32, vp]
+    lib.orc_max_threads.restype = i32
+    return lib
+
+
+lib = _load()
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+class SceneRef:
+    """Keeps the ctypes structs (and the numpy arrays behind them) alive."""
+
+    def __init__(self, scene):
+        self.scene = scene
+        self.tex = (OrcTexture * max(1, len(scene.textures)))()
+        for i, t in enumerate(scene.textures):
+            self.tex[i].rgba8 = t.ctypes.data
+            self.tex[i].width = t.shape[1]
+            self.tex[i].height = t.shape[0]
+        self.s = OrcScene(_p(scene.spheres), len(scene.spheres), _p(scene.quads), len(scene.quads), _p(scene.tris),
+                          len(scene.tris), _p(scene.materials), len(scene.materials),
+                          C.cast(self.tex, C.c_void_p) if scene.textures else None, len(scene.textures))
+        self.w = None
+        if scene.world is not None:
+            offs, prims, is_list = scene.world
+            self.w = OrcWorld(len(is_list), _p(offs), _p(prims), _p(is_list))
+
+
+def render(scene, params_list, width, height, flags=TRAVERSE_FAST, max_bounces=0, threads=0, accum=None, build_bvh=None,
+           want_ids=True):
+    """Run len(params_list) dispatches on the CPU oracle.  Returns (accum[h,w,4], ids[h,w], counters)."""
+    ref = SceneRef(scene)
+    params = np.ascontiguousarray(np.concatenate([np.asarray(p).reshape(1) for p in params_list]))
+    assert params.dtype.itemsize == 112
+    if accum is None:
+        accum = np.zeros((height, width, 4), dtype=np.float32)
+    ids = np.full((height, width), 0xFFFFFFFF, dtype=np.uint32) if want_ids else None
+    cnt = OrcCounters()
+    bb = None
+    if build_bvh is not None:
+        nodes, sid, qid, tid = build_bvh
+        bb = OrcBuildBvh(_p(nodes), len(nodes), _p(sid), _p(qid), _p(tid))
+    rc = lib.orc_render(C.byref(ref.s), C.byref(ref.w) if ref.w is not None else None, C.byref(bb) if bb is not None else None,
+                        _p(params), len(params), width, height, flags, max_bounces, threads, _p(accum), _p(ids) if want_ids else None,
+                        C.byref(cnt))
+    if rc != 0:
+        raise RuntimeError(f"orc_render failed: {rc}")
+    return accum, ids, cnt
+
+
+def ref_bvh(scene):
+    """The reference's serialized BVH for scene.world: (nodes[64 B], sphere_ids, quad_ids, tri_ids)."""
+    from computeraytracer_amd.abi import ref_node_dtype
+    ref = SceneRef(scene)
+    n = [C.c_uint32() for _ in range(4)]
+    lib.orc_ref_bvh(C.byref(ref.s), C.byref(ref.w), None, C.byref(n[0]), None, C.byref(n[1]), None, C.byref(n[2]), None, C.byref(n[3]))
+    nodes = np.zeros(n[0].value, dtype=ref_node_dtype)
+    ids = [np.zeros(n[i].value, dtype=np.uint32) for i in (1, 2, 3)]
+    lib.orc_ref_bvh(C.byref(ref.s), C.byref(ref.w), _p(nodes), C.byref(n[0]), _p(ids[0]), C.byref(n[1]), _p(ids[1]), C.byref(n[2]),
+                    _p(ids[2]), C.byref(n[3]))
+    return nodes, ids[0], ids[1], ids[2]
+
+
+def math_fn(fn, a, b=None, libm=False):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b if b is not None else np.zeros_like(a), dtype=np.float32)
+    o0, o1 = np.zeros_like(a), np.zeros_like(a)
+    lib.orc_math(fn, a.size, _p(a), _p(b), _p(o0), _p(o1), int(libm))
+    return o0, o1
+
+
+def glibc_rand(n, seed=1):
+    out = np.zeros(n, dtype=np.int32)
+    lib.orc_glibc_rand(seed, n, _p(out))
+    return out
