@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of the path tracer on the BASELINE.json workload.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--tracer megakernel|wavefront]
+
+A "step" is one dispatch of the hot path = one sample per pixel over the whole frame (what one
+vkCmdDispatch does in the reference, engine/src/vk_engine.cpp:1435).  The default workload is the one
+BASELINE.json's metric is quoted on, lost_empire 4K: lost_empire.obj is absent from the reference
+checkout, so the documented stand-in `voxel_city(seed=1)` (224,998 triangles, one atlas texture) is
+rendered at 3840x2160 and labelled as such.  With N > 1 (launched by torch.distributed.run, one rank per
+GPU) the frame's 8-row bands are dealt round-robin over the ranks ("strong" scaling: the frame is fixed),
+every rank holds the whole scene + BVH, and the finished image is gathered with one RCCL all-gather after
+the timed steps (its time is reported as config.gather_ms, outside `value`).
+
+rays = hit_world calls (primary + every bounce segment), counted on the device.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from computeraytracer_amd import abi  # noqa: E402
+
+WORKLOADS = {
+    # name: (scene, width, height, label)
+    "lost_empire_4k": ("voxel_city", 3840, 2160, "lost_empire 4K stand-in voxel_city(seed=1), 224998 tris"),
+    "monkey_1080p": ("monkey", 1920, 1080, "monkey_smooth.obj 1080p + ground sphere"),
+    "cirno_1080p": ("cirno", 1920, 1080, "cirno_low.obj textured 1080p (earthmap substitutes the missing texture)"),
+    "book1_400x225": ("book1", 400, 225, "RTIOW spheres 400x225"),
+    "grid10m_1080p": ("grid10m", 1920, 1080, "10M-triangle instanced grid, per-frame LBVH rebuild"),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(scene, target_s=12.0):
+    """The CPU oracle (kind "port": there is no CPU tracer in the reference) on a bounded sample of the
+    same scene/camera/seeds: 256x144, as many iterations as fit ~target_s, all host threads the box gives us."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc   # the measured baseline, never the product
+    w, h = 256, 144
+    small = abi.builtin_scene(scene.name, w, h, os.path.join(ROOT, "tests", "golden"))
+    threads = min(orc.lib.orc_max_threads(), int(os.environ.get("OMP_NUM_THREADS", "16")))
+    seeds = abi.frame_seeds(0, 2049)
+    t0 = time.perf_counter()
+    _, _, c = orc.render(small, [small.params_for(1, seeds[0])], w, h, flags=orc.TRAVERSE_FAST, threads=threads, want_ids=False)
+    one = time.perf_counter() - t0
+    n = int(max(1, min(2048, target_s / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    _, _, c = orc.render(small, [small.params_for(i + 2, seeds[i + 1]) for i in range(n)], w, h, flags=orc.TRAVERSE_FAST,
+                         threads=threads, want_ids=False)
+    dt = time.perf_counter() - t0
+    return {"value": round(c.rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{small.name} {w}x{h} x {n} iterations ({c.rays} rays, {dt:.1f} s), oracle TRAVERSE_FAST, OpenMP"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--workload", default="lost_empire_4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--tracer", default=os.environ.get("CRT_TRACER", "megakernel"), choices=["megakernel", "wavefront"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    scene_name, W, H, label = WORKLOADS[args.workload]
+    scene = abi.builtin_scene(scene_name, W, H, os.path.join(ROOT, "tests", "golden"))
+    tracer = abi.TRACER_WAVEFRONT if args.tracer == "wavefront" else abi.TRACER_MEGAKERNEL
+    rebuild = args.workload == "grid10m_1080p"
+
+    ctx = abi.Context(local_rank)
+    ctx.configure(W, H, tracer=tracer, band_rank=rank, band_world=world)
+    ctx.upload(scene)
+    build_ms = ctx.build()
+    build_ms = ctx.build()            # second build: allocations are warm, this is the device time of the build alone
+    seeds = abi.frame_seeds(0, args.warmup + args.steps + 1)
+
+    def run(first_iter, n):
+        if not rebuild:
+            ctx.render(scene.params, first_iter, seeds[first_iter - 1:first_iter - 1 + n])
+            return
+        for i in range(n):            # config 5: animate + full rebuild every frame, one sample per frame
+            ctx.animate(float(first_iter + i), 0.35)
+            ctx.build()
+            ctx.render(scene.params, 1, seeds[first_iter - 1 + i:first_iter + i])
+
+    # V, T, D for the bytes-per-ray model: one instrumented dispatch (untimed)
+    ctx.stats_reset()
+    ctx.set_instrumented(True)
+    run(1, 1)
+    ctx.sync()
+    st = ctx.stats()
+    ctx.set_instrumented(False)
+    V = st.node_visits / max(st.rays, 1)
+    T = st.prim_tests / max(st.rays, 1)
+    D = st.rays / max(st.paths, 1)
+
+    run(1, args.warmup)
+    ctx.sync()
+    ctx.stats_reset()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            import torch
+            torch.cuda.synchronize()
+        ctx.sync()
+
+    barrier()
+    t0 = time.perf_counter()
+    run(args.warmup + 1, args.steps)
+    ctx.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    rays = float(st.rays)
+    kernel_ms = st.last_render_ms     # HIP events on the context's stream around the timed launches (last run() call)
+
+    gather_ms = None
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed, rays], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, rays = float(tmax[0]), float(t[1])
+        # gather the finished image: one all-gather of the packed band buffers
+        ptr, nbytes = ctx.image_device_ptr()
+        counts = torch.tensor([nbytes], dtype=torch.int64, device="cuda")
+        allc = [torch.zeros_like(counts) for _ in range(world)]
+        dist.all_gather(allc, counts)
+        maxb = int(max(int(c) for c in allc))
+        mine = torch.zeros(maxb // 4, dtype=torch.float32, device="cuda")
+        ctx.image_copy_to_device(mine.data_ptr(), nbytes)
+        out = torch.empty(world * (maxb // 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize(); dist.barrier()
+        g0 = time.perf_counter()
+        dist.all_gather_into_tensor(out, mine)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    if rank == 0:
+        mrays = rays / elapsed / 1e6
+        bytes_per_ray = 32.0 * V + 48.0 * T + (128.0 if tracer == abi.TRACER_WAVEFRONT else 0.0) + 32.0 / D
+        # dominant kernel: the tracer.  algorithmic bytes per launch = rays per launch x bytes/ray (rank 0's share)
+        rank_rays = float(st.rays)
+        launch_ms = kernel_ms / args.steps if not rebuild else kernel_ms
+        launch_rays = rank_rays / args.steps
+        achieved = launch_rays * bytes_per_ray / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        line = {
+            "metric": "Mrays/s (whole node) lost_empire 4K 256spp; BVH build ms; RMSE vs ref",
+            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": label, "scene": scene_name, "width": W, "height": H, "spp_per_step": 1,
+                       "tris": int(len(scene.tris)), "spheres": int(len(scene.spheres)), "quads": int(len(scene.quads)),
+                       "tracer": args.tracer, "rng": "ref-hash", "parallelism": f"tile{world}" if world > 1 else "single",
+                       "bvh_build_ms": round(build_ms, 4), "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+                       "rays_per_path": round(D, 3), "nodes_per_ray": round(V, 2), "prim_tests_per_ray": round(T, 2)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "k_megakernel" if tracer == abi.TRACER_MEGAKERNEL else "k_wf_extend",
+                         "bytes_per_ray": round(bytes_per_ray, 1), "launch_ms": round(launch_ms, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(scene)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -92,6 +92,7 @@ def _load():
         "crt_image_read": (i32, [vp, vp, C.c_size_t]),
         "crt_hit_ids_read": (i32, [vp, vp, C.c_size_t]),
         "crt_image_device_ptr": (i32, [vp, P(vp), P(C.c_size_t)]),
+        "crt_image_copy_to_device": (i32, [vp, vp, C.c_size_t]),
         "crt_band_rows": (u32, [u32, u32, u32, vp]),
         "crt_stats_read": (i32, [vp, P(Stats)]),
         "crt_stats_reset": (i32, [vp]),
@@ -322,6 +323,9 @@ class Context:
         p, n = C.c_void_p(), C.c_size_t()
         self._check(lib.crt_image_device_ptr(self._h, C.byref(p), C.byref(n)), "crt_image_device_ptr")
         return p.value, n.value
+
+    def image_copy_to_device(self, device_ptr, n_bytes):
+        self._check(lib.crt_image_copy_to_device(self._h, C.c_void_p(device_ptr), n_bytes), "crt_image_copy_to_device")
 
     def stats(self):
         s = Stats()

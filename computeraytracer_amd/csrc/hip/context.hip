@@ -362,6 +362,16 @@ int crt_image_device_ptr(crt_context *ctx, void **device_ptr, size_t *n_bytes) {
     return CRT_OK;
 }
 
+int crt_image_copy_to_device(crt_context *ctx, void *dst_device, size_t n_bytes) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!ctx->configured) return fail(ctx, CRT_ERR_INVALID, "crt_image_copy_to_device: not configured");
+    if (!dst_device || n_bytes != (size_t)ctx->local_rows * ctx->cfg.width * 16)
+        return fail(ctx, CRT_ERR_INVALID, "crt_image_copy_to_device: destination must hold exactly the band buffer");
+    CTX_HIP(hipMemcpyAsync(dst_device, ctx->accum.ptr, n_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    CTX_HIP(hipStreamSynchronize(ctx->stream));
+    return CRT_OK;
+}
+
 int crt_stats_read(crt_context *ctx, crt_stats *out) {
     int rc = bind(ctx); if (rc) return rc;
     if (!out) return fail(ctx, CRT_ERR_INVALID, "crt_stats_read: null output");

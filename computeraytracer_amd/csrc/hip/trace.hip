@@ -104,9 +104,10 @@ __global__ __launch_bounds__(256) void k_megakernel(DeviceScene sc, Frame f, flo
     }
     rays = wave_sum(rays);
     if (COUNT) { nodes = wave_sum(nodes); prims = wave_sum(prims); }
+    const unsigned long long n_active = (unsigned long long)__popcll(__ballot(active));
     if (lane == 0 && tile < f.n_tiles) {
         atomicAdd(&stats->rays, rays);
-        atomicAdd(&stats->paths, (unsigned long long)__popcll(__ballot(active)));
+        atomicAdd(&stats->paths, n_active);
         if (COUNT) { atomicAdd(&stats->node_visits, nodes); atomicAdd(&stats->prim_tests, prims); }
     }
 }

@@ -101,6 +101,9 @@ int crt_hit_ids_read(crt_context *ctx, uint32_t *ids, size_t n_ids);
  * gather (RCCL all-gather over xGMI in the multi-GPU harness).  With
  * band_world <= 1 this is the whole image. */
 int crt_image_device_ptr(crt_context *ctx, void **device_ptr, size_t *n_bytes);
+/* Copies the packed band buffer into caller-owned device memory (e.g. a torch
+ * tensor that RCCL will gather) and waits for the copy. */
+int crt_image_copy_to_device(crt_context *ctx, void *dst_device, size_t n_bytes);
 /* Rows owned by (band_rank, band_world) for a given height: writes the y of
  * each owned row in increasing order; returns the count (rows may be NULL). */
 uint32_t crt_band_rows(uint32_t height, uint32_t band_rank, uint32_t band_world, uint32_t *rows);

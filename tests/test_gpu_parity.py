@@ -1,0 +1,114 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar: primary-hit IDs identical and the raw accumulation image BIT-EXACT.  The build fixes every
+transcendental as an explicit FP32 sequence (DESIGN.md "Arithmetic"), so there is no tolerance to
+state: any differing bit is a bug.
+"""
+import numpy as np
+import pytest
+
+from computeraytracer_amd import abi
+import oracle_lib as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = abi.Context(0)
+    yield c
+    c.close()
+
+
+def _params(scene, n):
+    seeds = abi.frame_seeds(0, n)
+    return [scene.params_for(i + 1, seeds[i]) for i in range(n)], seeds
+
+
+def _gpu_render(ctx, scene, w, h, n_iter, **cfg):
+    ctx.configure(w, h, **cfg)
+    ctx.upload(scene)
+    ctx.build()
+    ps, seeds = _params(scene, n_iter)
+    ctx.render(ps[0], 1, seeds)
+    ctx.sync()
+    return ctx.image(), ctx.hit_ids(), ps
+
+
+CASES = [("quads", 64, 64, 3), ("corne", 96, 96, 4), ("book1", 200, 112, 3), ("voxel_city", 160, 96, 2), ("grid:2", 96, 64, 2)]
+
+
+@pytest.mark.parametrize("name,w,h,n_iter", CASES)
+def test_megakernel_bit_exact(ctx, name, w, h, n_iter):
+    scene = abi.builtin_scene(name, w, h)
+    img, ids, ps = _gpu_render(ctx, scene, w, h, n_iter)
+    ref_img, ref_ids, cnt = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_FAST)
+    assert (ids != ref_ids).sum() == 0, f"{(ids != ref_ids).sum()} primary-hit ID mismatches"
+    diff = img.view(np.uint32) != ref_img.view(np.uint32)
+    assert diff.sum() == 0, f"{diff.any(axis=2).sum()} pixels differ, max abs {np.abs(img - ref_img).max()}"
+    assert ctx.stats().rays >= cnt.rays   # stats accumulate over the module
+
+
+def test_pcg_mode_bit_exact(ctx):
+    scene = abi.builtin_scene("book1", 128, 72)
+    img, ids, ps = _gpu_render(ctx, scene, 128, 72, 3, rng_mode=abi.RNG_PCG)
+    ref_img, ref_ids, _ = orc.render(scene, ps, 128, 72, flags=orc.TRAVERSE_FAST | orc.RNG_PCG)
+    assert np.array_equal(ids, ref_ids)
+    assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32))
+
+
+def test_full_image_flag_and_ragged_size(ctx):
+    # 100 x 50 is not a multiple of 8: default renders 96 x 48 (dispatch(W/8, H/8, 1)), the flag renders all
+    scene = abi.builtin_scene("corne", 100, 50)
+    img, ids, ps = _gpu_render(ctx, scene, 100, 50, 2)
+    ref_img, ref_ids, _ = orc.render(scene, ps, 100, 50, flags=orc.TRAVERSE_FAST)
+    assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32)) and np.array_equal(ids, ref_ids)
+    assert not img[48:].any() and not img[:, 96:].any()
+    img, ids, ps = _gpu_render(ctx, scene, 100, 50, 2, flags=abi.FLAG_FULL_IMAGE)
+    ref_img, ref_ids, _ = orc.render(scene, ps, 100, 50, flags=orc.TRAVERSE_FAST | orc.FULL_IMAGE)
+    assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32)) and np.array_equal(ids, ref_ids)
+
+
+def test_device_bvh_traversed_by_oracle(ctx):
+    # the oracle walks the BVH the device built: same hits as its own tree => the device tree loses nothing
+    scene = abi.builtin_scene("book1", 96, 56)
+    ctx.configure(96, 56)
+    ctx.upload(scene)
+    ctx.build()
+    bvh = ctx.bvh()
+    ps, _ = _params(scene, 1)
+    a, i, _ = orc.render(scene, ps, 96, 56, flags=orc.TRAVERSE_BUILD, build_bvh=bvh)
+    b, j, _ = orc.render(scene, ps, 96, 56, flags=orc.TRAVERSE_BRUTE)
+    assert np.array_equal(i, j) and np.array_equal(a, b)
+
+
+def test_empty_and_single_primitive_scenes(ctx):
+    empty = abi.HostScene(params=abi.builtin_scene("quads", 32, 32).params, materials=abi.builtin_scene("quads", 32, 32).materials)
+    img, ids, ps = _gpu_render(ctx, empty, 32, 32, 1)
+    ref_img, ref_ids, _ = orc.render(empty, ps, 32, 32, flags=orc.TRAVERSE_BRUTE)
+    assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32)) and (ids == abi.ID_MISS).all()
+    q = abi.builtin_scene("quads", 32, 32)
+    single = abi.HostScene(quads=q.quads[1:2], materials=q.materials, params=q.params)
+    img, ids, ps = _gpu_render(ctx, single, 32, 32, 2)
+    ref_img, ref_ids, _ = orc.render(single, ps, 32, 32, flags=orc.TRAVERSE_BRUTE)
+    assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32)) and np.array_equal(ids, ref_ids)
+
+
+def test_errors_are_reported_not_fatal():
+    q = abi.builtin_scene("quads", 32, 32)
+    with abi.Context(0) as c:
+        with pytest.raises(abi.CrtError, match="crt_configure has not been called"):
+            c.dispatch(q.params)
+        c.configure(32, 32)
+        bad = abi.HostScene(quads=q.quads, materials=q.materials[:1], params=q.params)
+        with pytest.raises(abi.CrtError, match="material index"):
+            c.upload(bad)
+        with pytest.raises(abi.CrtError, match="crt_scene_upload has not been called"):
+            c.dispatch(q.params)
+        c.upload(q)
+        with pytest.raises(abi.CrtError, match="crt_bvh_build has not been called"):
+            c.dispatch(q.params)
+        with pytest.raises(abi.CrtError):
+            c.configure(0, 32)
+    with pytest.raises(abi.CrtError, match="no usable HIP device"):
+        abi.Context(4096)
