@@ -140,20 +140,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed, rays = float(tmax[0]), float(t[1])
-        # gather the finished image: one all-gather of the packed band buffers
-        ptr, nbytes = ctx.image_device_ptr()
-        counts = torch.tensor([nbytes], dtype=torch.int64, device="cuda")
-        allc = [torch.zeros_like(counts) for _ in range(world)]
-        dist.all_gather(allc, counts)
-        maxb = int(max(int(c) for c in allc))
-        mine = torch.zeros(maxb // 4, dtype=torch.float32, device="cuda")
-        ctx.image_copy_to_device(mine.data_ptr(), nbytes)
-        out = torch.empty(world * (maxb // 4), dtype=torch.float32, device="cuda")
+        # gather the finished image: one all-gather of the packed band buffers + un-interleave (dist.py)
+        from computeraytracer_amd import dist as cdist
+        band = cdist.context_band_tensor(ctx, W, torch.device("cuda", local_rank))
         torch.cuda.synchronize(); dist.barrier()
         g0 = time.perf_counter()
-        dist.all_gather_into_tensor(out, mine)
+        image = cdist.gather_image(band, H, world)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        assert tuple(image.shape) == (H, W, 4)
 
     if rank == 0:
         mrays = rays / elapsed / 1e6

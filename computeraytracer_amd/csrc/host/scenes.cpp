@@ -63,7 +63,7 @@ static void bind_textures(SceneBuilder &b, const std::string &asset_dir, const s
     for (const std::string &name : b.texture_names) {
         std::vector<uint8_t> px; uint32_t w = 0, h = 0; bool ok = false;
         for (const auto &kv : files) {
-            if (kv.first != name || asset_dir.empty()) continue;
+            if (ok || kv.first != name || asset_dir.empty()) continue;
             std::string err;
             ok = load_texture_file(asset_dir + "/" + kv.second, px, w, h, err);
         }

@@ -112,3 +112,75 @@ def test_errors_are_reported_not_fatal():
             c.configure(0, 32)
     with pytest.raises(abi.CrtError, match="no usable HIP device"):
         abi.Context(4096)
+
+
+def test_committed_golden_renders_on_gpu(ctx, golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "oracle_vectors.npz"))
+    for name in ["book1", "corne", "quads", "cirno", "monkey"]:
+        w, h, n = (int(v) for v in g[f"{name}_shape"])
+        scene = abi.builtin_scene(name, w, h, golden_dir)
+        img, ids, _ = _gpu_render(ctx, scene, w, h, n)
+        assert np.array_equal(ids, g[f"{name}_ids"]), name
+        assert np.array_equal(img.view(np.uint32), g[f"{name}_img"].view(np.uint32)), name
+
+
+def test_band_sharded_contexts_assemble_to_the_single_context_image(golden_dir):
+    # the multi-GPU partition, rehearsed on one GPU: three contexts each render their 8-row bands
+    from computeraytracer_amd import dist as cdist
+    w, h, n, world = 120, 100, 3, 3
+    scene = abi.builtin_scene("cirno", w, h, golden_dir)
+    seeds = abi.frame_seeds(0, n)
+    with abi.Context(0) as whole:
+        whole.configure(w, h, flags=abi.FLAG_FULL_IMAGE)
+        whole.upload(scene); whole.build()
+        whole.render(scene.params, 1, seeds); whole.sync()
+        want, want_ids = whole.image(), whole.hit_ids()
+    got = np.zeros_like(want)
+    got_ids = np.full_like(want_ids, abi.ID_MISS)
+    rays = 0
+    for r in range(world):
+        with abi.Context(0) as c:
+            c.configure(w, h, flags=abi.FLAG_FULL_IMAGE, band_rank=r, band_world=world)
+            c.upload(scene); c.build()
+            c.render(scene.params, 1, seeds); c.sync()
+            img, ids = c.image(), c.hit_ids()
+            rows = abi.band_rows(h, r, world)
+            assert not np.delete(img, rows, axis=0).any()          # a rank writes only its own rows
+            got[rows] = img[rows]; got_ids[rows] = ids[rows]
+            _, nbytes = c.image_device_ptr()
+            assert nbytes == cdist.local_rows(h, r, world) * w * 16
+            rays += c.stats().rays
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and np.array_equal(got_ids, want_ids)
+
+
+def test_render_equals_repeated_dispatch(ctx):
+    scene = abi.builtin_scene("corne", 64, 64)
+    img, ids, ps = _gpu_render(ctx, scene, 64, 64, 3)
+    ctx.configure(64, 64)
+    for p in ps:
+        ctx.dispatch(p)
+    ctx.sync()
+    assert np.array_equal(ctx.image().view(np.uint32), img.view(np.uint32))
+    # continuing an accumulation later (checkpoint/resume = the image itself)
+    seeds = abi.frame_seeds(3, 2)
+    ctx.render(scene.params, 4, seeds)
+    ctx.sync()
+    five = ctx.image()
+    ref, _, _ = orc.render(scene, ps + [scene.params_for(4, seeds[0]), scene.params_for(5, seeds[1])], 64, 64)
+    assert np.array_equal(five.view(np.uint32), ref.view(np.uint32)) and (five[..., 3] == 5).all()
+
+
+def test_stats_count_hit_world_calls(ctx):
+    scene = abi.builtin_scene("book1", 96, 56)
+    ctx.configure(96, 56)
+    ctx.upload(scene); ctx.build()
+    ctx.stats_reset()
+    ps, seeds = _params(scene, 2)
+    ctx.set_instrumented(True)
+    ctx.render(ps[0], 1, seeds); ctx.sync()
+    ctx.set_instrumented(False)
+    st = ctx.stats()
+    _, _, cnt = orc.render(scene, ps, 96, 56, flags=orc.TRAVERSE_FAST)
+    assert st.rays == cnt.rays and st.paths == cnt.paths == 2 * 96 * 56
+    assert st.node_visits > st.rays and st.prim_tests > 0 and st.last_render_ms > 0
