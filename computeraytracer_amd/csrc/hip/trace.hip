@@ -132,10 +132,181 @@ bool launch_megakernel(hipStream_t stream, const DeviceSceneHost &sch, const Fra
     return true;
 }
 
-bool launch_wavefront(hipStream_t, const DeviceSceneHost &, const FrameSetup &, const crt_scene_params &, WavefrontState &,
-                      float *, uint32_t *, DeviceStats *, std::string &err) {
-    err = "wavefront tracer not built yet";
-    return false;
+// ------------------------------------------------------------------------------------------------
+// Wavefront tracer.  One dispatch = generate -> [extend -> shade+compact] x max_bounces.
+//
+//   queue entry (64 B, SoA over four float4 arrays, two queues used ping-pong):
+//     ray_o = {origin.xyz, -}            ray_d = {direction.xyz, pixel slot in the packed band buffer}
+//     thr   = {color.rgb, rng word 0}    emi   = {emittedColor.rgb, rng word 1}
+//   hit[i] = {t, id} of queue entry i (8 B), written by extend, read by shade.
+//   counters[b] = number of live paths entering bounce b; work[b] = extend's work-fetch cursor.
+//
+// extend is persistent: a fixed grid of waves pulls 64-ray batches with one atomic per batch until the
+// queue is drained, so a late bounce with few rays costs one short launch instead of a full grid.
+// shade ends a path by doing main()'s read-modify-write of the accumulation pixel directly (each pixel
+// owns exactly one path per dispatch), and appends survivors to the other queue with a wave ballot +
+// prefix count and a single atomic per wave.
+// ------------------------------------------------------------------------------------------------
+struct WfQueues {
+    float4 *ray_o[2], *ray_d[2], *thr[2], *emi[2];
+    uint2 *hit;
+    uint32_t *counters;     // [0 .. 15] queue sizes per bounce, [16 .. 31] extend work cursors
+};
+
+template <int RNGM>
+__global__ __launch_bounds__(256) void k_wf_generate(Frame f, WfQueues q, DeviceStats *stats) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    uint32_t x = 0, y = 0, prow = 0;
+    bool active = tile < f.n_tiles && tile_pixel(f, tile, lane, x, y, prow);
+    const unsigned long long mask = __ballot(active);
+    if (mask == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) {
+        base = atomicAdd(&q.counters[0], (uint32_t)__popcll(mask));
+        atomicAdd(&stats->paths, (unsigned long long)__popcll(mask));
+    }
+    base = __shfl(base, 0);
+    if (!active) return;
+    const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const crt_camera_data &cam = f.p.camera;
+    Rng<RNGM> rng;
+    rng.init(cam.seed, x, y, y * f.width + x, cam.iteration);
+    float ox, oy; hash_2(rng, ox, oy);
+    float u = ((float)x + ox) / (float)f.width, v = ((float)y + oy) / (float)f.height;
+    V3 o, d;
+    camera_get_ray(cam, u, v, rng, o, d);
+    const uint64_t rs = rng.pack();
+    q.ray_o[0][slot] = make_float4(o.x, o.y, o.z, 0.0f);
+    q.ray_d[0][slot] = make_float4(d.x, d.y, d.z, u2f(prow * f.width + x));
+    q.thr[0][slot] = make_float4(1.0f, 1.0f, 1.0f, u2f((uint32_t)rs));
+    q.emi[0][slot] = make_float4(0.0f, 0.0f, 0.0f, u2f((uint32_t)(rs >> 32)));
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_wf_extend(DeviceScene sc, WfQueues q, uint32_t bounce, DeviceStats *stats) {
+    __shared__ uint32_t s_stack[kLdsStack * 256];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = q.counters[bounce];
+    const float4 *ro = q.ray_o[bounce & 1], *rd = q.ray_d[bounce & 1];
+    unsigned long long nodes = 0, prims = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays, (unsigned long long)n);
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&q.counters[16 + bounce], 64u);
+        base = __shfl(base, 0);
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        if (i < n) {
+            float4 o4 = ro[i], d4 = rd[i];
+            float t; uint32_t id; Counts cnt = {0, 0};
+            closest_hit<COUNT>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), s_stack + threadIdx.x, 256, t, id, cnt);
+            q.hit[i] = make_uint2(f2u(t), id);
+            if (COUNT) { nodes += cnt.nodes; prims += cnt.prims; }
+        }
+    }
+    if (COUNT) {
+        nodes = wave_sum(nodes); prims = wave_sum(prims);
+        if (lane == 0) { atomicAdd(&stats->node_visits, nodes); atomicAdd(&stats->prim_tests, prims); }
+    }
+}
+
+template <int RNGM>
+__global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, Frame f, WfQueues q, uint32_t bounce, float4 *accum, uint32_t *hit_ids) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = q.counters[bounce];
+    const uint32_t in = bounce & 1, out = in ^ 1;
+    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const bool last = bounce + 1 >= f.max_bounces;
+    for (uint32_t base = wave_id * 64; base < n; base += n_waves * 64) {
+        const uint32_t i = base + lane;
+        bool alive = false;
+        V3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), color = mk3(0, 0, 0), emitted = mk3(0, 0, 0);
+        uint32_t pix = 0;
+        Rng<RNGM> rng;
+        if (i < n) {
+            float4 o4 = q.ray_o[in][i], d4 = q.ray_d[in][i], c4 = q.thr[in][i], e4 = q.emi[in][i];
+            uint2 h = q.hit[i];
+            o = mk3(o4.x, o4.y, o4.z); d = mk3(d4.x, d4.y, d4.z);
+            color = mk3(c4.x, c4.y, c4.z); emitted = mk3(e4.x, e4.y, e4.z);
+            pix = f2u(d4.w);
+            rng.unpack((uint64_t)f2u(c4.w) | ((uint64_t)f2u(e4.w) << 32), f.pcg_inc);
+            const float t = u2f(h.x); const uint32_t id = h.y;
+            if (bounce == 0) hit_ids[pix] = id;
+            V3 pass = mk3(0.0f, 0.0f, 0.0f);
+            if (id == kIdMiss) pass = shade_miss(f.p, d, color);
+            else alive = shade_hit(sc, o, d, t, id, rng, color, emitted, pass);
+            if (alive && last) { alive = false; pass = mk3(0.0f, 0.0f, 0.0f); }     // "Kill ray after MAX_BOUNCES", compute.comp:457
+            if (!alive) {                                                            // main(), :470-476
+                pass = pass * (1.0f / 1.0f);
+                float4 cum4 = accum[pix];
+                V3 cum = accumulate(mk3(cum4.x, cum4.y, cum4.z), pass, f.p.camera.iteration);
+                accum[pix] = make_float4(cum.x, cum.y, cum.z, f.p.camera.iteration);
+            }
+        }
+        const unsigned long long mask = __ballot(alive);
+        if (mask == 0) continue;
+        uint32_t obase = 0;
+        if (lane == 0) obase = atomicAdd(&q.counters[bounce + 1], (uint32_t)__popcll(mask));
+        obase = __shfl(obase, 0);
+        if (alive) {
+            const uint32_t slot = obase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            const uint64_t rs = rng.pack();
+            q.ray_o[out][slot] = make_float4(o.x, o.y, o.z, 0.0f);
+            q.ray_d[out][slot] = make_float4(d.x, d.y, d.z, u2f(pix));
+            q.thr[out][slot] = make_float4(color.x, color.y, color.z, u2f((uint32_t)rs));
+            q.emi[out][slot] = make_float4(emitted.x, emitted.y, emitted.z, u2f((uint32_t)(rs >> 32)));
+        }
+    }
+}
+
+static bool ensure_dev(DeviceBuffer &b, size_t bytes, std::string &err) {
+    if (b.ptr && b.bytes >= bytes) return true;
+    if (b.ptr) { hipError_t e = hipFree(b.ptr); (void)e; b.ptr = nullptr; b.bytes = 0; }
+    size_t want = bytes < 256 ? 256 : bytes;
+    HIP_TRY(hipMalloc(&b.ptr, want));
+    b.bytes = want;
+    return true;
+}
+
+bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const FrameSetup &fs, const crt_scene_params &params,
+                      WavefrontState &wf, float *accum, uint32_t *hit_ids, DeviceStats *stats, std::string &err) {
+    DeviceScene sc = to_device_scene(sch);
+    Frame f = make_frame(fs, params);
+    if (f.n_tiles == 0) return true;
+    if (f.max_bounces > 15) { err = "wavefront tracer supports at most 15 bounces"; return false; }
+    const uint32_t cap = f.n_tiles * 64;
+    if (wf.capacity < cap) {
+        for (int k = 0; k < 2; k++) {
+            if (!ensure_dev(wf.ray_o[k], (size_t)cap * 16, err) || !ensure_dev(wf.ray_d[k], (size_t)cap * 16, err) ||
+                !ensure_dev(wf.thr[k], (size_t)cap * 16, err) || !ensure_dev(wf.emi[k], (size_t)cap * 16, err)) return false;
+        }
+        if (!ensure_dev(wf.hit, (size_t)cap * 8, err) || !ensure_dev(wf.counters, 32 * 4, err)) return false;
+        wf.capacity = cap;
+    }
+    WfQueues q;
+    for (int k = 0; k < 2; k++) {
+        q.ray_o[k] = (float4 *)wf.ray_o[k].ptr; q.ray_d[k] = (float4 *)wf.ray_d[k].ptr;
+        q.thr[k] = (float4 *)wf.thr[k].ptr; q.emi[k] = (float4 *)wf.emi[k].ptr;
+    }
+    q.hit = (uint2 *)wf.hit.ptr; q.counters = (uint32_t *)wf.counters.ptr;
+    HIP_TRY(hipMemsetAsync(q.counters, 0, 32 * 4, stream));
+    float4 *acc = (float4 *)accum;
+    const dim3 block(256), gen_grid((f.n_tiles + 3) / 4);
+    // persistent grids: 256 CUs x 6 resident blocks (LDS stack: 24 KiB per block)
+    const uint32_t full = (cap + 255) / 256;
+    const dim3 pgrid(full < 1536u ? full : 1536u);
+    const bool pcg = fs.rng_mode != CRT_RNG_REF;
+    if (pcg) hipLaunchKernelGGL((k_wf_generate<1>), gen_grid, block, 0, stream, f, q, stats);
+    else hipLaunchKernelGGL((k_wf_generate<0>), gen_grid, block, 0, stream, f, q, stats);
+    for (uint32_t b = 0; b < f.max_bounces; b++) {
+        if (fs.instrumented) hipLaunchKernelGGL((k_wf_extend<true>), pgrid, block, 0, stream, sc, q, b, stats);
+        else hipLaunchKernelGGL((k_wf_extend<false>), pgrid, block, 0, stream, sc, q, b, stats);
+        if (pcg) hipLaunchKernelGGL((k_wf_shade<1>), pgrid, block, 0, stream, sc, f, q, b, acc, hit_ids);
+        else hipLaunchKernelGGL((k_wf_shade<0>), pgrid, block, 0, stream, sc, f, q, b, acc, hit_ids);
+    }
+    HIP_TRY(hipGetLastError());
+    return true;
 }
 
 void free_wavefront(WavefrontState &wf) {

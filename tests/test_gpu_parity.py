@@ -38,10 +38,11 @@ def _gpu_render(ctx, scene, w, h, n_iter, **cfg):
 CASES = [("quads", 64, 64, 3), ("corne", 96, 96, 4), ("book1", 200, 112, 3), ("voxel_city", 160, 96, 2), ("grid:2", 96, 64, 2)]
 
 
+@pytest.mark.parametrize("tracer", [abi.TRACER_MEGAKERNEL, abi.TRACER_WAVEFRONT], ids=["megakernel", "wavefront"])
 @pytest.mark.parametrize("name,w,h,n_iter", CASES)
-def test_megakernel_bit_exact(ctx, name, w, h, n_iter):
+def test_tracers_bit_exact(ctx, name, w, h, n_iter, tracer):
     scene = abi.builtin_scene(name, w, h)
-    img, ids, ps = _gpu_render(ctx, scene, w, h, n_iter)
+    img, ids, ps = _gpu_render(ctx, scene, w, h, n_iter, tracer=tracer)
     ref_img, ref_ids, cnt = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_FAST)
     assert (ids != ref_ids).sum() == 0, f"{(ids != ref_ids).sum()} primary-hit ID mismatches"
     diff = img.view(np.uint32) != ref_img.view(np.uint32)
@@ -49,22 +50,24 @@ def test_megakernel_bit_exact(ctx, name, w, h, n_iter):
     assert ctx.stats().rays >= cnt.rays   # stats accumulate over the module
 
 
-def test_pcg_mode_bit_exact(ctx):
+@pytest.mark.parametrize("tracer", [abi.TRACER_MEGAKERNEL, abi.TRACER_WAVEFRONT], ids=["megakernel", "wavefront"])
+def test_pcg_mode_bit_exact(ctx, tracer):
     scene = abi.builtin_scene("book1", 128, 72)
-    img, ids, ps = _gpu_render(ctx, scene, 128, 72, 3, rng_mode=abi.RNG_PCG)
+    img, ids, ps = _gpu_render(ctx, scene, 128, 72, 3, rng_mode=abi.RNG_PCG, tracer=tracer)
     ref_img, ref_ids, _ = orc.render(scene, ps, 128, 72, flags=orc.TRAVERSE_FAST | orc.RNG_PCG)
     assert np.array_equal(ids, ref_ids)
     assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32))
 
 
-def test_full_image_flag_and_ragged_size(ctx):
+@pytest.mark.parametrize("tracer", [abi.TRACER_MEGAKERNEL, abi.TRACER_WAVEFRONT], ids=["megakernel", "wavefront"])
+def test_full_image_flag_and_ragged_size(ctx, tracer):
     # 100 x 50 is not a multiple of 8: default renders 96 x 48 (dispatch(W/8, H/8, 1)), the flag renders all
     scene = abi.builtin_scene("corne", 100, 50)
-    img, ids, ps = _gpu_render(ctx, scene, 100, 50, 2)
+    img, ids, ps = _gpu_render(ctx, scene, 100, 50, 2, tracer=tracer)
     ref_img, ref_ids, _ = orc.render(scene, ps, 100, 50, flags=orc.TRAVERSE_FAST)
     assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32)) and np.array_equal(ids, ref_ids)
     assert not img[48:].any() and not img[:, 96:].any()
-    img, ids, ps = _gpu_render(ctx, scene, 100, 50, 2, flags=abi.FLAG_FULL_IMAGE)
+    img, ids, ps = _gpu_render(ctx, scene, 100, 50, 2, flags=abi.FLAG_FULL_IMAGE, tracer=tracer)
     ref_img, ref_ids, _ = orc.render(scene, ps, 100, 50, flags=orc.TRAVERSE_FAST | orc.FULL_IMAGE)
     assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32)) and np.array_equal(ids, ref_ids)
 
@@ -120,7 +123,7 @@ def test_committed_golden_renders_on_gpu(ctx, golden_dir):
     for name in ["book1", "corne", "quads", "cirno", "monkey"]:
         w, h, n = (int(v) for v in g[f"{name}_shape"])
         scene = abi.builtin_scene(name, w, h, golden_dir)
-        img, ids, _ = _gpu_render(ctx, scene, w, h, n)
+        img, ids, _ = _gpu_render(ctx, scene, w, h, n, tracer=abi.TRACER_WAVEFRONT)
         assert np.array_equal(ids, g[f"{name}_ids"]), name
         assert np.array_equal(img.view(np.uint32), g[f"{name}_img"].view(np.uint32)), name
 
