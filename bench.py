@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="lost_empire_4k", choices=sorted(WORKLOADS))
-    ap.add_argument("--tracer", default=os.environ.get("CRT_TRACER", "megakernel"), choices=["megakernel", "wavefront"])
+    ap.add_argument("--tracer", default=os.environ.get("CRT_TRACER", "wavefront"), choices=["megakernel", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

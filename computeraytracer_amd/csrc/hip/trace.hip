@@ -9,6 +9,8 @@
 // Built with -ffp-contract=off; see device_math.h for the arithmetic contract.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "build_internal.h"
 #include "shade.h"
 
@@ -133,42 +135,69 @@ bool launch_megakernel(hipStream_t stream, const DeviceSceneHost &sch, const Fra
 }
 
 // ------------------------------------------------------------------------------------------------
-// Wavefront tracer.  One dispatch = generate -> [extend -> shade+compact] x max_bounces.
+// Wavefront tracer.  One dispatch = init -> generate -> [extend -> shade+compact] x max_bounces.
 //
 //   queue entry (64 B, SoA over four float4 arrays, two queues used ping-pong):
 //     ray_o = {origin.xyz, -}            ray_d = {direction.xyz, pixel slot in the packed band buffer}
 //     thr   = {color.rgb, rng word 0}    emi   = {emittedColor.rgb, rng word 1}
 //   hit[i] = {t, id} of queue entry i (8 B), written by extend, read by shade.
-//   counters[b] = number of live paths entering bounce b; work[b] = extend's work-fetch cursor.
 //
-// extend is persistent: a fixed grid of waves pulls 64-ray batches with one atomic per batch until the
-// queue is drained, so a late bounce with few rays costs one short launch instead of a full grid.
+// The queue is split into kShards sub-queues (contiguous runs of 8x8 tiles).  A path never leaves its
+// sub-queue, so a sub-queue's capacity is its initial size and every sub-queue has its own size and
+// work-cursor words: one returning atomic on ONE word saturates near 88 per microsecond on this chip
+// (MI355X_MICROARCH.md, "dequeue"), which at one atomic per 64 rays capped a single-counter version of
+// this design at ~5.6 Grays/s before any traversal work.
+//
+// extend is persistent: a fixed grid of waves pulls 64-ray batches from its home sub-queue, then steals
+// from the others, until everything is drained; a late bounce with few rays costs one short launch.
 // shade ends a path by doing main()'s read-modify-write of the accumulation pixel directly (each pixel
-// owns exactly one path per dispatch), and appends survivors to the other queue with a wave ballot +
-// prefix count and a single atomic per wave.
+// owns exactly one path per dispatch) and appends survivors to the other queue with a wave ballot +
+// prefix count and a single atomic per wave on the sub-queue's own counter.
 // ------------------------------------------------------------------------------------------------
+constexpr uint32_t kShards = 64;
+constexpr uint32_t kMaxBounces = 16;
+constexpr uint32_t kCtrStride = 64;    // one counter per 256 bytes: neighbouring words share an L2 line and serialise their atomics
+constexpr uint32_t kFetchBatches = 4;  // at most this many 64-ray batches per work-fetch atomic
+
 struct WfQueues {
     float4 *ray_o[2], *ray_d[2], *thr[2], *emi[2];
     uint2 *hit;
-    uint32_t *counters;     // [0 .. 15] queue sizes per bounce, [16 .. 31] extend work cursors
+    uint32_t *counts;       // [kMaxBounces + 1][kShards] live paths entering bounce b in sub-queue s
+    uint32_t *cursors;      // [kMaxBounces][kShards]     extend's work-fetch cursor
+    uint32_t tiles_per_shard, shard_cap;   // shard_cap = tiles_per_shard * 64 slots
+    uint32_t n_shards;                     // sub-queues in use (<= kShards)
+    uint32_t precheck;                     // experiment knob: load the cursor before the fetch atomic
 };
 
+constexpr uint32_t kDeadPixel = 0xFFFFFFFFu;   // queue entry of a lane outside the rendered grid (ragged sizes only)
+
+__global__ void k_wf_init(WfQueues q, uint32_t n_tiles, unsigned long long n_active, DeviceStats *stats) {
+    for (uint32_t i = threadIdx.x; i < (kMaxBounces + 1) * kShards; i += blockDim.x) {
+        uint32_t v = 0;
+        if (i < q.n_shards) {
+            uint32_t t0 = i * q.tiles_per_shard, t1 = min(n_tiles, t0 + q.tiles_per_shard);
+            v = t1 > t0 ? (t1 - t0) * 64u : 0u;
+        }
+        q.counts[i * kCtrStride] = v;
+    }
+    for (uint32_t i = threadIdx.x; i < kMaxBounces * kShards; i += blockDim.x) q.cursors[i * kCtrStride] = 0;
+    if (threadIdx.x == 0) atomicAdd(&stats->paths, n_active);
+}
+
 template <int RNGM>
-__global__ __launch_bounds__(256) void k_wf_generate(Frame f, WfQueues q, DeviceStats *stats) {
+__global__ __launch_bounds__(256) void k_wf_generate(Frame f, WfQueues q) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    if (tile >= f.n_tiles) return;
     uint32_t x = 0, y = 0, prow = 0;
-    bool active = tile < f.n_tiles && tile_pixel(f, tile, lane, x, y, prow);
-    const unsigned long long mask = __ballot(active);
-    if (mask == 0) return;
-    uint32_t base = 0;
-    if (lane == 0) {
-        base = atomicAdd(&q.counters[0], (uint32_t)__popcll(mask));
-        atomicAdd(&stats->paths, (unsigned long long)__popcll(mask));
+    const bool active = tile_pixel(f, tile, lane, x, y, prow);
+    const uint32_t shard = tile / q.tiles_per_shard;
+    const uint32_t slot = shard * q.shard_cap + (tile - shard * q.tiles_per_shard) * 64 + lane;
+    if (!active) {
+        q.ray_o[0][slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        q.ray_d[0][slot] = make_float4(0.0f, 0.0f, 1.0f, u2f(kDeadPixel));
+        return;
     }
-    base = __shfl(base, 0);
-    if (!active) return;
-    const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     const crt_camera_data &cam = f.p.camera;
     Rng<RNGM> rng;
     rng.init(cam.seed, x, y, y * f.width + x, cam.iteration);
@@ -183,26 +212,55 @@ __global__ __launch_bounds__(256) void k_wf_generate(Frame f, WfQueues q, Device
     q.emi[0][slot] = make_float4(0.0f, 0.0f, 0.0f, u2f((uint32_t)(rs >> 32)));
 }
 
+// Home sub-queue of a wave: blocks b and b + 8 share an XCD (and its L2), so the waves of one XCD start on
+// sub-queues congruent to it modulo 8, i.e. on the same stretch of the image.
+__device__ __forceinline__ uint32_t home_shard(uint32_t block, uint32_t wave, uint32_t n_shards) {
+    if (n_shards < 8) return block % n_shards;
+    return (block % 8) + 8 * (((block / 8) * 4 + wave) % (n_shards / 8));
+}
+
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_wf_extend(DeviceScene sc, WfQueues q, uint32_t bounce, DeviceStats *stats) {
+__global__ __launch_bounds__(256) void k_wf_extend(DeviceScene sc, WfQueues q, uint32_t bounce, unsigned long long dead, DeviceStats *stats) {
     __shared__ uint32_t s_stack[kLdsStack * 256];
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t n = q.counters[bounce];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t *counts = q.counts + bounce * kShards * kCtrStride;
+    uint32_t *cursors = q.cursors + bounce * kShards * kCtrStride;
     const float4 *ro = q.ray_o[bounce & 1], *rd = q.ray_d[bounce & 1];
     unsigned long long nodes = 0, prims = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays, (unsigned long long)n);
-    for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&q.counters[16 + bounce], 64u);
-        base = __shfl(base, 0);
-        if (base >= n) break;
-        const uint32_t i = base + lane;
-        if (i < n) {
-            float4 o4 = ro[i], d4 = rd[i];
-            float t; uint32_t id; Counts cnt = {0, 0};
-            closest_hit<COUNT>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), s_stack + threadIdx.x, 256, t, id, cnt);
-            q.hit[i] = make_uint2(f2u(t), id);
-            if (COUNT) { nodes += cnt.nodes; prims += cnt.prims; }
+    if (blockIdx.x == 0 && threadIdx.x < kShards) {
+        unsigned long long n = wave_sum((unsigned long long)counts[threadIdx.x * kCtrStride]);
+        if (threadIdx.x == 0) atomicAdd(&stats->rays, n - dead);
+    }
+    const uint32_t ns = q.n_shards, per = ns >= 8 ? ns / 8 : 1;
+    const uint32_t home = home_shard(blockIdx.x, wave, ns);
+    for (uint32_t k = 0; k < ns; k++) {
+        // steal order: own sub-queue, then the others of this XCD's residue class, then the rest
+        const uint32_t s = ns >= 8 ? (home + 8 * (k % per) + (k / per)) % ns : (home + k) % ns;
+        const uint32_t n = counts[s * kCtrStride];
+        if (n == 0) continue;
+        uint32_t *cursor = cursors + s * kCtrStride;
+        // fetch granularity: up to kFetchBatches batches per atomic while the sub-queue is long (the atomic rate
+        // matters), single batches once it is short (load balance matters: a late bounce has ~1 batch per wave)
+        const uint32_t waves_here = max(1u, (gridDim.x * 4u) / ns);
+        const uint32_t fetch = min(kFetchBatches, max(1u, n / (waves_here * 64u * 8u)));
+        for (;;) {
+            // a stale (cached) cursor value can only be too small, so it never skips live work
+            uint32_t base = n;
+            if (lane == 0 && (!q.precheck || *(volatile uint32_t *)cursor < n)) base = atomicAdd(cursor, 64u * fetch);
+            base = __shfl(base, 0);
+            if (base >= n) break;
+            for (uint32_t bb = 0; bb < fetch; bb++) {
+                const uint32_t i = base + bb * 64 + lane;
+                if (i < n) {
+                    const uint32_t slot = s * q.shard_cap + i;
+                    float4 o4 = ro[slot], d4 = rd[slot];
+                    float t = kInf; uint32_t id = kIdMiss; Counts cnt = {0, 0};
+                    if (f2u(d4.w) != kDeadPixel)
+                        closest_hit<COUNT>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), s_stack + threadIdx.x, 256, t, id, cnt);
+                    q.hit[slot] = make_uint2(f2u(t), id);
+                    if (COUNT) { nodes += cnt.nodes; prims += cnt.prims; }
+                }
+            }
         }
     }
     if (COUNT) {
@@ -214,43 +272,51 @@ __global__ __launch_bounds__(256) void k_wf_extend(DeviceScene sc, WfQueues q, u
 template <int RNGM>
 __global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, Frame f, WfQueues q, uint32_t bounce, float4 *accum, uint32_t *hit_ids) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t n = q.counters[bounce];
     const uint32_t in = bounce & 1, out = in ^ 1;
+    // waves are dealt round-robin over the sub-queues; shading cost per path is near uniform, so no stealing
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t s = wave_id % q.n_shards, wave_in_shard = wave_id / q.n_shards, waves_per_shard = n_waves / q.n_shards;
+    if (wave_in_shard >= waves_per_shard) return;
+    const uint32_t n = q.counts[(bounce * kShards + s) * kCtrStride];
+    uint32_t *out_count = q.counts + ((bounce + 1) * kShards + s) * kCtrStride;
     const bool last = bounce + 1 >= f.max_bounces;
-    for (uint32_t base = wave_id * 64; base < n; base += n_waves * 64) {
+    for (uint32_t base = wave_in_shard * 64; base < n; base += waves_per_shard * 64) {
         const uint32_t i = base + lane;
         bool alive = false;
         V3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), color = mk3(0, 0, 0), emitted = mk3(0, 0, 0);
-        uint32_t pix = 0;
+        uint32_t pix = kDeadPixel;
         Rng<RNGM> rng;
         if (i < n) {
-            float4 o4 = q.ray_o[in][i], d4 = q.ray_d[in][i], c4 = q.thr[in][i], e4 = q.emi[in][i];
-            uint2 h = q.hit[i];
-            o = mk3(o4.x, o4.y, o4.z); d = mk3(d4.x, d4.y, d4.z);
-            color = mk3(c4.x, c4.y, c4.z); emitted = mk3(e4.x, e4.y, e4.z);
+            const uint32_t slot = s * q.shard_cap + i;
+            float4 d4 = q.ray_d[in][slot];
             pix = f2u(d4.w);
-            rng.unpack((uint64_t)f2u(c4.w) | ((uint64_t)f2u(e4.w) << 32), f.pcg_inc);
-            const float t = u2f(h.x); const uint32_t id = h.y;
-            if (bounce == 0) hit_ids[pix] = id;
-            V3 pass = mk3(0.0f, 0.0f, 0.0f);
-            if (id == kIdMiss) pass = shade_miss(f.p, d, color);
-            else alive = shade_hit(sc, o, d, t, id, rng, color, emitted, pass);
-            if (alive && last) { alive = false; pass = mk3(0.0f, 0.0f, 0.0f); }     // "Kill ray after MAX_BOUNCES", compute.comp:457
-            if (!alive) {                                                            // main(), :470-476
-                pass = pass * (1.0f / 1.0f);
-                float4 cum4 = accum[pix];
-                V3 cum = accumulate(mk3(cum4.x, cum4.y, cum4.z), pass, f.p.camera.iteration);
-                accum[pix] = make_float4(cum.x, cum.y, cum.z, f.p.camera.iteration);
+            if (pix != kDeadPixel) {
+                float4 o4 = q.ray_o[in][slot], c4 = q.thr[in][slot], e4 = q.emi[in][slot];
+                uint2 h = q.hit[slot];
+                o = mk3(o4.x, o4.y, o4.z); d = mk3(d4.x, d4.y, d4.z);
+                color = mk3(c4.x, c4.y, c4.z); emitted = mk3(e4.x, e4.y, e4.z);
+                rng.unpack((uint64_t)f2u(c4.w) | ((uint64_t)f2u(e4.w) << 32), f.pcg_inc);
+                const float t = u2f(h.x); const uint32_t id = h.y;
+                if (bounce == 0) hit_ids[pix] = id;
+                V3 pass = mk3(0.0f, 0.0f, 0.0f);
+                if (id == kIdMiss) pass = shade_miss(f.p, d, color);
+                else alive = shade_hit(sc, o, d, t, id, rng, color, emitted, pass);
+                if (alive && last) { alive = false; pass = mk3(0.0f, 0.0f, 0.0f); }     // "Kill ray after MAX_BOUNCES", compute.comp:457
+                if (!alive) {                                                            // main(), :470-476
+                    pass = pass * (1.0f / 1.0f);
+                    float4 cum4 = accum[pix];
+                    V3 cum = accumulate(mk3(cum4.x, cum4.y, cum4.z), pass, f.p.camera.iteration);
+                    accum[pix] = make_float4(cum.x, cum.y, cum.z, f.p.camera.iteration);
+                }
             }
         }
         const unsigned long long mask = __ballot(alive);
         if (mask == 0) continue;
         uint32_t obase = 0;
-        if (lane == 0) obase = atomicAdd(&q.counters[bounce + 1], (uint32_t)__popcll(mask));
+        if (lane == 0) obase = atomicAdd(out_count, (uint32_t)__popcll(mask));
         obase = __shfl(obase, 0);
         if (alive) {
-            const uint32_t slot = obase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            const uint32_t slot = s * q.shard_cap + obase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             const uint64_t rs = rng.pack();
             q.ray_o[out][slot] = make_float4(o.x, o.y, o.z, 0.0f);
             q.ray_d[out][slot] = make_float4(d.x, d.y, d.z, u2f(pix));
@@ -274,34 +340,53 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     DeviceScene sc = to_device_scene(sch);
     Frame f = make_frame(fs, params);
     if (f.n_tiles == 0) return true;
-    if (f.max_bounces > 15) { err = "wavefront tracer supports at most 15 bounces"; return false; }
-    const uint32_t cap = f.n_tiles * 64;
+    if (f.max_bounces > kMaxBounces) { err = "wavefront tracer supports at most 16 bounces"; return false; }
+    WfQueues q;
+    static const uint32_t env_shards = [] { const char *e = getenv("CRT_WF_SHARDS"); int v = e ? atoi(e) : 16;
+                                            return (uint32_t)((v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? v : 16); }();
+    q.n_shards = env_shards;
+    static const uint32_t env_precheck = [] { const char *e = getenv("CRT_WF_PRECHECK"); return (uint32_t)(e ? atoi(e) : 1); }();
+    q.precheck = env_precheck;
+    q.tiles_per_shard = (f.n_tiles + q.n_shards - 1) / q.n_shards;
+    q.shard_cap = q.tiles_per_shard * 64;
+    const uint32_t cap = q.shard_cap * q.n_shards;
     if (wf.capacity < cap) {
         for (int k = 0; k < 2; k++) {
             if (!ensure_dev(wf.ray_o[k], (size_t)cap * 16, err) || !ensure_dev(wf.ray_d[k], (size_t)cap * 16, err) ||
                 !ensure_dev(wf.thr[k], (size_t)cap * 16, err) || !ensure_dev(wf.emi[k], (size_t)cap * 16, err)) return false;
         }
-        if (!ensure_dev(wf.hit, (size_t)cap * 8, err) || !ensure_dev(wf.counters, 32 * 4, err)) return false;
+        if (!ensure_dev(wf.hit, (size_t)cap * 8, err) || !ensure_dev(wf.counters, (size_t)(2 * kMaxBounces + 1) * kShards * kCtrStride * 4, err)) return false;
         wf.capacity = cap;
     }
-    WfQueues q;
     for (int k = 0; k < 2; k++) {
         q.ray_o[k] = (float4 *)wf.ray_o[k].ptr; q.ray_d[k] = (float4 *)wf.ray_d[k].ptr;
         q.thr[k] = (float4 *)wf.thr[k].ptr; q.emi[k] = (float4 *)wf.emi[k].ptr;
     }
-    q.hit = (uint2 *)wf.hit.ptr; q.counters = (uint32_t *)wf.counters.ptr;
-    HIP_TRY(hipMemsetAsync(q.counters, 0, 32 * 4, stream));
+    q.hit = (uint2 *)wf.hit.ptr;
+    q.counts = (uint32_t *)wf.counters.ptr;
+    q.cursors = q.counts + (kMaxBounces + 1) * kShards * kCtrStride;
+    // active pixels of this context: every owned band is full height except possibly the image's last band
+    unsigned long long n_active = 0;
+    for (uint32_t lb = 0; lb < fs.n_local_bands; lb++) {
+        uint32_t y0 = (lb * fs.band_world + fs.band_rank) * 8;
+        uint32_t rows = y0 < fs.grid_h ? (fs.grid_h - y0 < 8 ? fs.grid_h - y0 : 8) : 0;
+        n_active += (unsigned long long)rows * fs.grid_w;
+    }
+    const unsigned long long dead = (unsigned long long)f.n_tiles * 64 - n_active;
     float4 *acc = (float4 *)accum;
     const dim3 block(256), gen_grid((f.n_tiles + 3) / 4);
-    // persistent grids: 256 CUs x 6 resident blocks (LDS stack: 24 KiB per block)
-    const uint32_t full = (cap + 255) / 256;
-    const dim3 pgrid(full < 1536u ? full : 1536u);
+    // persistent grids: 256 CUs x 6 resident blocks (LDS stack: 24 KiB per block); multiple of 8 blocks and of kShards waves
+    uint32_t nb = (cap + 255) / 256;
+    nb = nb < 1536u ? ((nb + 15) / 16) * 16 : 1536u;
+    const dim3 pgrid(nb);
     const bool pcg = fs.rng_mode != CRT_RNG_REF;
-    if (pcg) hipLaunchKernelGGL((k_wf_generate<1>), gen_grid, block, 0, stream, f, q, stats);
-    else hipLaunchKernelGGL((k_wf_generate<0>), gen_grid, block, 0, stream, f, q, stats);
+    hipLaunchKernelGGL(k_wf_init, dim3(1), dim3(256), 0, stream, q, f.n_tiles, n_active, stats);
+    if (pcg) hipLaunchKernelGGL((k_wf_generate<1>), gen_grid, block, 0, stream, f, q);
+    else hipLaunchKernelGGL((k_wf_generate<0>), gen_grid, block, 0, stream, f, q);
     for (uint32_t b = 0; b < f.max_bounces; b++) {
-        if (fs.instrumented) hipLaunchKernelGGL((k_wf_extend<true>), pgrid, block, 0, stream, sc, q, b, stats);
-        else hipLaunchKernelGGL((k_wf_extend<false>), pgrid, block, 0, stream, sc, q, b, stats);
+        const unsigned long long dead_b = b == 0 ? dead : 0ull;
+        if (fs.instrumented) hipLaunchKernelGGL((k_wf_extend<true>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
+        else hipLaunchKernelGGL((k_wf_extend<false>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
         if (pcg) hipLaunchKernelGGL((k_wf_shade<1>), pgrid, block, 0, stream, sc, f, q, b, acc, hit_ids);
         else hipLaunchKernelGGL((k_wf_shade<0>), pgrid, block, 0, stream, sc, f, q, b, acc, hit_ids);
     }
