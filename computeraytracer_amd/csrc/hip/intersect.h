@@ -175,6 +175,54 @@ CRT_DEV void closest_hit(const DeviceScene &sc, V3 o, V3 d, uint32_t *stack, uin
     }
 }
 
+// The same traversal as closest_hit, cut into single steps so that a persistent wave can give a lane a new
+// ray the moment its old one finishes (k_wf_extend) instead of idling until the slowest lane of the wave is done.
+struct Traversal {
+    V3 o, d, idir, noid;
+    float best_t, tfar;
+    uint32_t best_id, cur;
+    int sp;
+};
+
+CRT_DEV void trav_begin(Traversal &tr, V3 o, V3 d) {
+    tr.o = o; tr.d = d;
+    tr.idir.x = __builtin_fabsf(d.x) > 1e-30f ? 1.0f / d.x : __builtin_copysignf(1e30f, d.x);
+    tr.idir.y = __builtin_fabsf(d.y) > 1e-30f ? 1.0f / d.y : __builtin_copysignf(1e30f, d.y);
+    tr.idir.z = __builtin_fabsf(d.z) > 1e-30f ? 1.0f / d.z : __builtin_copysignf(1e30f, d.z);
+    tr.noid = mk3(-(o.x * tr.idir.x), -(o.y * tr.idir.y), -(o.z * tr.idir.z));
+    tr.best_t = kInf; tr.tfar = kInf; tr.best_id = kIdMiss; tr.cur = 0; tr.sp = 0;
+}
+
+// One pair visit.  Returns false when the traversal is finished (best_t / best_id are final).
+template <bool COUNT>
+CRT_DEV bool trav_step(const DeviceScene &sc, Traversal &tr, uint32_t *stack, uint32_t stack_stride, uint32_t *spill, Counts &cnt) {
+    const float4 *p = sc.nodes + 4 * (size_t)tr.cur;
+    float4 lo0 = p[0], hi0 = p[1], lo1 = p[2], hi1 = p[3];
+    if (COUNT) cnt.nodes += 2;
+    float tn0, tn1;
+    bool h0 = slab(lo0, hi0, tr.idir, tr.noid, tr.tfar, tn0);
+    bool h1 = slab(lo1, hi1, tr.idir, tr.noid, tr.tfar, tn1);
+    uint32_t c0 = f2u(hi0.w), c1 = f2u(hi1.w);
+    if (h0 && c0 != 0) { test_leaf<COUNT>(sc, tr.o, tr.d, f2u(lo0.w), c0, tr.best_t, tr.best_id, cnt); h0 = false; }
+    if (h1 && c1 != 0) { test_leaf<COUNT>(sc, tr.o, tr.d, f2u(lo1.w), c1, tr.best_t, tr.best_id, cnt); h1 = false; }
+    tr.tfar = tr.best_t * 1.000004f;
+    uint32_t l0 = f2u(lo0.w), l1 = f2u(lo1.w);
+    if (h0 && h1) {
+        bool first0 = tn0 <= tn1;
+        uint32_t nearc = first0 ? l0 : l1, farc = first0 ? l1 : l0;
+        if (tr.sp < kLdsStack) stack[tr.sp * stack_stride] = farc; else if (tr.sp < kLdsStack + kSpillStack) spill[tr.sp - kLdsStack] = farc;
+        tr.sp++;
+        tr.cur = nearc;
+    } else if (h0) tr.cur = l0;
+    else if (h1) tr.cur = l1;
+    else {
+        if (tr.sp == 0) return false;
+        tr.sp--;
+        tr.cur = tr.sp < kLdsStack ? stack[tr.sp * stack_stride] : spill[tr.sp - kLdsStack];
+    }
+    return true;
+}
+
 // The shader's HitRecord (compute.comp:195-203), rebuilt for the winning primitive from the
 // uploaded arrays with the same arithmetic hit_sphere/hit_quad/hit_tri use at the moment of the hit.
 // (In hit_tri the invDet/beta/gamma are functions of the ray and the triangle only, so evaluating

@@ -219,6 +219,12 @@ __device__ __forceinline__ uint32_t home_shard(uint32_t block, uint32_t wave, ui
     return (block % 8) + 8 * (((block / 8) * 4 + wave) % (n_shards / 8));
 }
 
+// Persistent extend with per-lane refill.  Each wave owns a pool [pool_next, pool_end) of queue slots fetched from a
+// sub-queue cursor; whenever at least kRefillLanes lanes are idle they take the next slots of the pool (ballot +
+// prefix popcount), so lanes do not wait for the slowest ray of a batch.  Every wave reaches the exit: the pool can
+// only be refilled from cursors that grow monotonically up to fixed sizes.
+constexpr uint32_t kRefillLanes = 16;
+
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_wf_extend(DeviceScene sc, WfQueues q, uint32_t bounce, unsigned long long dead, DeviceStats *stats) {
     __shared__ uint32_t s_stack[kLdsStack * 256];
@@ -231,36 +237,72 @@ __global__ __launch_bounds__(256) void k_wf_extend(DeviceScene sc, WfQueues q, u
         unsigned long long n = wave_sum((unsigned long long)counts[threadIdx.x * kCtrStride]);
         if (threadIdx.x == 0) atomicAdd(&stats->rays, n - dead);
     }
+    if (sc.n_pairs == 0) {      // empty scene: every ray misses
+        for (uint32_t s = 0; s < q.n_shards; s++) {
+            const uint32_t n = counts[s * kCtrStride];
+            for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+                q.hit[s * q.shard_cap + i] = make_uint2(f2u(kInf), kIdMiss);
+        }
+        return;
+    }
     const uint32_t ns = q.n_shards, per = ns >= 8 ? ns / 8 : 1;
     const uint32_t home = home_shard(blockIdx.x, wave, ns);
-    for (uint32_t k = 0; k < ns; k++) {
-        // steal order: own sub-queue, then the others of this XCD's residue class, then the rest
-        const uint32_t s = ns >= 8 ? (home + 8 * (k % per) + (k / per)) % ns : (home + k) % ns;
-        const uint32_t n = counts[s * kCtrStride];
-        if (n == 0) continue;
-        uint32_t *cursor = cursors + s * kCtrStride;
-        // fetch granularity: up to kFetchBatches batches per atomic while the sub-queue is long (the atomic rate
-        // matters), single batches once it is short (load balance matters: a late bounce has ~1 batch per wave)
-        const uint32_t waves_here = max(1u, (gridDim.x * 4u) / ns);
-        const uint32_t fetch = min(kFetchBatches, max(1u, n / (waves_here * 64u * 8u)));
-        for (;;) {
-            // a stale (cached) cursor value can only be too small, so it never skips live work
-            uint32_t base = n;
-            if (lane == 0 && (!q.precheck || *(volatile uint32_t *)cursor < n)) base = atomicAdd(cursor, 64u * fetch);
-            base = __shfl(base, 0);
-            if (base >= n) break;
-            for (uint32_t bb = 0; bb < fetch; bb++) {
-                const uint32_t i = base + bb * 64 + lane;
-                if (i < n) {
-                    const uint32_t slot = s * q.shard_cap + i;
-                    float4 o4 = ro[slot], d4 = rd[slot];
-                    float t = kInf; uint32_t id = kIdMiss; Counts cnt = {0, 0};
-                    if (f2u(d4.w) != kDeadPixel)
-                        closest_hit<COUNT>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), s_stack + threadIdx.x, 256, t, id, cnt);
-                    q.hit[slot] = make_uint2(f2u(t), id);
-                    if (COUNT) { nodes += cnt.nodes; prims += cnt.prims; }
+    const uint32_t waves_here = max(1u, (gridDim.x * 4u) / ns);
+    // wave-uniform work state
+    uint32_t k = 0;                       // position in the steal order
+    uint32_t pool_next = 0, pool_end = 0, pool_base = 0;   // slots pool_base + [pool_next, pool_end)
+    bool drained = false;
+    // per-lane state
+    bool busy = false;
+    uint32_t slot = 0;
+    Traversal tr;
+    uint32_t spill[kSpillStack];
+    uint32_t *stack = s_stack + threadIdx.x;
+    for (;;) {
+        const unsigned long long idle = __ballot(!busy);
+        if (!drained && (uint32_t)__popcll(idle) >= kRefillLanes) {
+            if (pool_next >= pool_end) {
+                // fetch the next chunk: own sub-queue first, then the others of this XCD's residue class, then the rest
+                while (k < ns) {
+                    const uint32_t s = ns >= 8 ? (home + 8 * (k % per) + (k / per)) % ns : (home + k) % ns;
+                    const uint32_t n = counts[s * kCtrStride];
+                    uint32_t base = n;
+                    if (n != 0) {
+                        // up to kFetchBatches batches per atomic while the sub-queue is long (atomic rate), one when it is short (balance)
+                        const uint32_t fetch = min(kFetchBatches, max(1u, n / (waves_here * 64u * 8u)));
+                        uint32_t *cursor = cursors + s * kCtrStride;
+                        // a stale (cached) cursor value can only be too small, so it never skips live work
+                        if (lane == 0 && *(volatile uint32_t *)cursor < n) base = atomicAdd(cursor, 64u * fetch);
+                        base = __shfl(base, 0);
+                        if (base < n) { pool_base = s * q.shard_cap; pool_next = base; pool_end = min(n, base + 64u * fetch); break; }
+                    }
+                    k++;
                 }
+                if (k >= ns) drained = true;
             }
+            if (!drained) {
+                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t i = pool_next + rank;
+                if (!busy && i < pool_end) {
+                    slot = pool_base + i;
+                    float4 o4 = ro[slot], d4 = rd[slot];
+                    if (f2u(d4.w) == kDeadPixel) q.hit[slot] = make_uint2(f2u(kInf), kIdMiss);
+                    else { trav_begin(tr, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z)); busy = true; }
+                }
+                pool_next = min(pool_end, pool_next + (uint32_t)__popcll(idle));
+            }
+        }
+        if (__ballot(busy) == 0) {
+            if (drained) break;
+            continue;
+        }
+        if (busy) {
+            Counts cnt = {0, 0};
+            if (!trav_step<COUNT>(sc, tr, stack, 256, spill, cnt)) {
+                q.hit[slot] = make_uint2(f2u(tr.best_t), tr.best_id);
+                busy = false;
+            }
+            if (COUNT) { nodes += cnt.nodes; prims += cnt.prims; }
         }
     }
     if (COUNT) {
