@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcrt.so")
+LIB_PATH = os.environ.get("CRT_LIB_PATH") or os.path.join(_HERE, "lib", "libcrt.so")   # override: A/B builds of the same ABI
 
 BAD_INDEX = 0xFFFFFFFF
 ID_MISS = 0xFFFFFFFF

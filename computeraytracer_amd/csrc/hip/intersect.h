@@ -29,8 +29,11 @@ struct DeviceScene {
     uint32_t n_textures;
 };
 
-constexpr int kLdsStack = 24;     // per-lane LDS stack entries; deeper levels spill to scratch
-constexpr int kSpillStack = 56;
+#ifndef CRT_LDS_STACK
+#define CRT_LDS_STACK 24
+#endif
+constexpr int kLdsStack = CRT_LDS_STACK;     // per-lane LDS stack entries; deeper levels spill to scratch
+constexpr int kSpillStack = 80 - CRT_LDS_STACK;
 constexpr uint32_t kIdMiss = 0xFFFFFFFFu;
 
 CRT_DEV bool accept_hit(float t, uint32_t id, float best_t, uint32_t best_id) {

@@ -167,6 +167,7 @@ struct WfQueues {
     uint32_t tiles_per_shard, shard_cap;   // shard_cap = tiles_per_shard * 64 slots
     uint32_t n_shards;                     // sub-queues in use (<= kShards)
     uint32_t precheck;                     // experiment knob: load the cursor before the fetch atomic
+    uint32_t refill;                       // idle lanes that trigger a refill
 };
 
 constexpr uint32_t kDeadPixel = 0xFFFFFFFFu;   // queue entry of a lane outside the rendered grid (ragged sizes only)
@@ -225,8 +226,11 @@ __device__ __forceinline__ uint32_t home_shard(uint32_t block, uint32_t wave, ui
 // only be refilled from cursors that grow monotonically up to fixed sizes.
 constexpr uint32_t kRefillLanes = 16;
 
+#ifndef CRT_EXTEND_WAVES
+#define CRT_EXTEND_WAVES 6
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_wf_extend(DeviceScene sc, WfQueues q, uint32_t bounce, unsigned long long dead, DeviceStats *stats) {
+__global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene sc, WfQueues q, uint32_t bounce, unsigned long long dead, DeviceStats *stats) {
     __shared__ uint32_t s_stack[kLdsStack * 256];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t *counts = q.counts + bounce * kShards * kCtrStride;
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256) void k_wf_extend(DeviceScene sc, WfQueues q, u
     uint32_t *stack = s_stack + threadIdx.x;
     for (;;) {
         const unsigned long long idle = __ballot(!busy);
-        if (!drained && (uint32_t)__popcll(idle) >= kRefillLanes) {
+        if (!drained && (uint32_t)__popcll(idle) >= q.refill) {
             if (pool_next >= pool_end) {
                 // fetch the next chunk: own sub-queue first, then the others of this XCD's residue class, then the rest
                 while (k < ns) {
@@ -389,6 +393,8 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     q.n_shards = env_shards;
     static const uint32_t env_precheck = [] { const char *e = getenv("CRT_WF_PRECHECK"); return (uint32_t)(e ? atoi(e) : 1); }();
     q.precheck = env_precheck;
+    static const uint32_t env_refill = [] { const char *e = getenv("CRT_WF_REFILL"); int v = e ? atoi(e) : (int)kRefillLanes; return (uint32_t)(v < 1 ? 1 : v > 64 ? 64 : v); }();
+    q.refill = env_refill;
     q.tiles_per_shard = (f.n_tiles + q.n_shards - 1) / q.n_shards;
     q.shard_cap = q.tiles_per_shard * 64;
     const uint32_t cap = q.shard_cap * q.n_shards;
@@ -419,7 +425,8 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     const dim3 block(256), gen_grid((f.n_tiles + 3) / 4);
     // persistent grids: 256 CUs x 6 resident blocks (LDS stack: 24 KiB per block); multiple of 8 blocks and of kShards waves
     uint32_t nb = (cap + 255) / 256;
-    nb = nb < 1536u ? ((nb + 15) / 16) * 16 : 1536u;
+    const uint32_t resident = 256u * CRT_EXTEND_WAVES;
+    nb = nb < resident ? ((nb + 15) / 16) * 16 : resident;
     const dim3 pgrid(nb);
     const bool pcg = fs.rng_mode != CRT_RNG_REF;
     hipLaunchKernelGGL(k_wf_init, dim3(1), dim3(256), 0, stream, q, f.n_tiles, n_active, stats);
