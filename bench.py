@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--workload", default="lost_empire_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--tracer", default=os.environ.get("CRT_TRACER", "wavefront"), choices=["megakernel", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bvh", default=os.environ.get("CRT_BVH", "lbvh"), choices=["lbvh", "sah"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,8 +88,9 @@ def main():
     ctx = abi.Context(local_rank)
     ctx.configure(W, H, tracer=tracer, band_rank=rank, band_world=world)
     ctx.upload(scene)
-    build_ms = ctx.build()
-    build_ms = ctx.build()            # second build: allocations are warm, this is the device time of the build alone
+    bvh_flags = abi.BVH_SAH_REFINE if args.bvh == "sah" else abi.BVH_LBVH
+    build_ms = ctx.build(bvh_flags)
+    build_ms = ctx.build(bvh_flags)   # second build: allocations are warm, this is the device time of the build alone
     seeds = abi.frame_seeds(0, args.warmup + args.steps + 1)
 
     def run(first_iter, n):
@@ -97,7 +99,7 @@ def main():
             return
         for i in range(n):            # config 5: animate + full rebuild every frame, one sample per frame
             ctx.animate(float(first_iter + i), 0.35)
-            ctx.build()
+            ctx.build(bvh_flags)
             ctx.render(scene.params, 1, seeds[first_iter - 1 + i:first_iter + i])
 
     # V, T, D for the bytes-per-ray model: one instrumented dispatch (untimed)
@@ -165,7 +167,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "scene": scene_name, "width": W, "height": H, "spp_per_step": 1,
                        "tris": int(len(scene.tris)), "spheres": int(len(scene.spheres)), "quads": int(len(scene.quads)),
-                       "tracer": args.tracer, "rng": "ref-hash", "parallelism": f"tile{world}" if world > 1 else "single",
+                       "tracer": args.tracer, "bvh": args.bvh, "rng": "ref-hash", "parallelism": f"tile{world}" if world > 1 else "single",
                        "bvh_build_ms": round(build_ms, 4), "gather_ms": None if gather_ms is None else round(gather_ms, 3),
                        "rays_per_path": round(D, 3), "nodes_per_ray": round(V, 2), "prim_tests_per_ray": round(T, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -21,7 +21,9 @@ struct BuildState {
     const uint32_t *sorted_vals = nullptr;
     // scratch
     DeviceBuffer plo, phi, keys, vals, keys_alt, vals_alt, flag_a, flag_b, rank_a, rank_b, leaf_link, leaf_count;
-    DeviceBuffer child_l, child_r, parent, nlo, nhi, scene_bounds, temp;
+    DeviceBuffer child_l, child_r, parent, nlo, nhi, ninfo, scene_bounds, temp;
+    // SAH leaf-collapse parameters (CRT_BVH_SAH_REFINE)
+    uint32_t max_leaf = 4; float c_isect = 1.0f, c_trav = 1.0f;
     // results (what traversal reads)
     DeviceBuffer pairs, tri_pack, sphere_pack, quad_pack, sphere_ids, quad_ids, tri_ids;
 };

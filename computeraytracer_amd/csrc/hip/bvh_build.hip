@@ -191,11 +191,29 @@ __global__ void k_hierarchy(int n, const uint32_t *keys, uint32_t *child_l, uint
     if (i == 0) parent[0] = 0xFFFFFFFFu;
 }
 
-// Child record inside its parent's pair.
-__device__ __forceinline__ void write_child(float4 *pair_half, int n, uint32_t child, float4 lo, float4 hi,
-                                            const uint32_t *leaf_link, const uint32_t *leaf_count) {
+// Per-subtree summary carried up by the refit: primitive count, SAH cost, kind (or kMixed), first leaf of its
+// (contiguous) range in sorted order, and whether the subtree is emitted as one multi-primitive leaf.
+constexpr uint32_t kMixed = 0xFFu;
+constexpr uint32_t kCollapsed = 0x100u;
+struct Sub { uint32_t count; float cost; uint32_t kind_flags; uint32_t first; };
+
+__device__ __forceinline__ float4 sub_pack(Sub s) {
+    return make_float4(__uint_as_float(s.count), s.cost, __uint_as_float(s.kind_flags), __uint_as_float(s.first));
+}
+__device__ __forceinline__ Sub sub_unpack(float4 v) {
+    Sub s; s.count = __float_as_uint(v.x); s.cost = v.y; s.kind_flags = __float_as_uint(v.z); s.first = __float_as_uint(v.w); return s;
+}
+__device__ __forceinline__ float half_area(float4 lo, float4 hi) {
+    float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+    return dx * dy + dy * dz + dx * dz;
+}
+
+// Child record inside its parent's pair: an inner child links to its own pair, a leaf (single primitive or a
+// collapsed subtree) to its first slot in the kind's sorted array.
+__device__ __forceinline__ void write_child(float4 *pair_half, int n, uint32_t child, float4 lo, float4 hi, Sub sub,
+                                            const uint32_t *leaf_link) {
     uint32_t link, count;
-    if (child >= (uint32_t)(n - 1)) { uint32_t s = child - (uint32_t)(n - 1); link = leaf_link[s]; count = leaf_count[s]; }
+    if (child >= (uint32_t)(n - 1) || (sub.kind_flags & kCollapsed)) { link = leaf_link[sub.first]; count = ((sub.kind_flags & 0xFFu) << 28) | sub.count; }
     else { link = child; count = 0u; }
     pair_half[0] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(link));
     pair_half[1] = make_float4(hi.x, hi.y, hi.z, __uint_as_float(count));
@@ -203,18 +221,27 @@ __device__ __forceinline__ void write_child(float4 *pair_half, int n, uint32_t c
 
 // Bottom-up refit.  One thread per leaf climbs; at each inner node the first arrival stops, the second
 // (which therefore knows both subtrees are finished) computes the node.  Cross-workgroup hand-off of
-// the sibling's box: stores, agent-scope fence (release), returning atomic; the winner fences again
+// the sibling's data: stores, agent-scope fence (release), returning atomic; the winner fences again
 // (acquire: invalidates this CU's L1) before loading what the other thread stored.
+//
+// SAH leaf collapse (CRT_BVH_SAH_REFINE): with C(leaf of n) = Ci * n * A and C(inner) = Ct * A + C(left) + C(right)
+// (A = surface area; entering a node costs one pair fetch + two slab tests = Ct), a subtree of one kind with at most
+// max_leaf primitives becomes a single leaf when that is not more expensive.  Its primitives are contiguous in the
+// sorted arrays because an LBVH subtree covers a contiguous Morton range.
 __global__ void k_refit_emit(int n, const uint32_t *vals, const float4 *plo, const float4 *phi,
                              const uint32_t *child_l, const uint32_t *child_r, const uint32_t *parent,
                              const uint32_t *leaf_link, const uint32_t *leaf_count,
-                             float4 *nlo, float4 *nhi, uint32_t *flags, float4 *pairs) {
+                             float4 *nlo, float4 *nhi, float4 *ninfo, uint32_t *flags, float4 *pairs,
+                             uint32_t max_leaf, float c_isect, float c_trav) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     uint32_t node = (uint32_t)(n - 1 + j);
     uint32_t g = vals[j];
     float4 lo = plo[g], hi = phi[g];
-    nlo[node] = lo; nhi[node] = hi;
+    Sub sub;
+    sub.count = 1; sub.kind_flags = leaf_count[j] >> 28; sub.first = (uint32_t)j;
+    sub.cost = c_isect * half_area(lo, hi);
+    nlo[node] = lo; nhi[node] = hi; ninfo[node] = sub_pack(sub);
     for (;;) {
         uint32_t p = parent[node];
         if (p == 0xFFFFFFFFu) break;
@@ -227,13 +254,26 @@ __global__ void k_refit_emit(int n, const uint32_t *vals, const float4 *plo, con
         uint32_t cl = child_l[p], cr = child_r[p];
         uint32_t sib = cl == node ? cr : cl;
         float4 slo = nlo[sib], shi = nhi[sib];
-        float4 l_lo = cl == node ? lo : slo, l_hi = cl == node ? hi : shi;
-        float4 r_lo = cl == node ? slo : lo, r_hi = cl == node ? shi : hi;
-        write_child(pairs + 4 * (size_t)p, n, cl, l_lo, l_hi, leaf_link, leaf_count);
-        write_child(pairs + 4 * (size_t)p + 2, n, cr, r_lo, r_hi, leaf_link, leaf_count);
+        Sub ssub = sub_unpack(ninfo[sib]);
+        bool mine_left = cl == node;
+        float4 l_lo = mine_left ? lo : slo, l_hi = mine_left ? hi : shi;
+        float4 r_lo = mine_left ? slo : lo, r_hi = mine_left ? shi : hi;
+        Sub l_sub = mine_left ? sub : ssub, r_sub = mine_left ? ssub : sub;
+        write_child(pairs + 4 * (size_t)p, n, cl, l_lo, l_hi, l_sub, leaf_link);
+        write_child(pairs + 4 * (size_t)p + 2, n, cr, r_lo, r_hi, r_sub, leaf_link);
         lo = make_float4(fminf(l_lo.x, r_lo.x), fminf(l_lo.y, r_lo.y), fminf(l_lo.z, r_lo.z), 0.0f);
         hi = make_float4(fmaxf(l_hi.x, r_hi.x), fmaxf(l_hi.y, r_hi.y), fmaxf(l_hi.z, r_hi.z), 0.0f);
-        nlo[p] = lo; nhi[p] = hi;
+        float area = half_area(lo, hi);
+        uint32_t lk = l_sub.kind_flags & 0xFFu, rk = r_sub.kind_flags & 0xFFu;
+        sub.count = l_sub.count + r_sub.count;
+        sub.first = l_sub.first;                       // the left child covers the lower part of the range
+        uint32_t kind = (lk == rk) ? lk : kMixed;
+        float as_inner = c_trav * area + l_sub.cost + r_sub.cost;
+        float as_leaf = c_isect * (float)sub.count * area;
+        bool collapse = kind != kMixed && sub.count <= max_leaf && as_leaf <= as_inner;
+        sub.cost = collapse ? as_leaf : as_inner;
+        sub.kind_flags = kind | (collapse ? kCollapsed : 0u);
+        nlo[p] = lo; nhi[p] = hi; ninfo[p] = sub_pack(sub);
         node = p;
     }
 }
@@ -294,7 +334,7 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     if (!ensure(st.leaf_link, (size_t)n * 4, err) || !ensure(st.leaf_count, (size_t)n * 4, err)) return false;
     if (!ensure(st.child_l, (size_t)n * 4, err) || !ensure(st.child_r, (size_t)n * 4, err)) return false;
     if (!ensure(st.parent, (size_t)(2 * (size_t)n) * 4, err)) return false;
-    if (!ensure(st.nlo, 2 * n4, err) || !ensure(st.nhi, 2 * n4, err)) return false;
+    if (!ensure(st.nlo, 2 * n4, err) || !ensure(st.nhi, 2 * n4, err) || !ensure(st.ninfo, 2 * n4, err)) return false;
     if (!ensure(st.scene_bounds, 64, err)) return false;
     if (!ensure(st.pairs, (size_t)st.n_pairs * 4 * sizeof(float4), err)) return false;
     if (!ensure(st.tri_pack, (size_t)in.n_tris * 3 * sizeof(float4), err)) return false;
@@ -349,15 +389,15 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     hipLaunchKernelGGL(k_refit_emit, dim3(blocks), dim3(256), 0, stream, (int)n, vals, (const float4 *)st.plo.ptr,
                        (const float4 *)st.phi.ptr, (const uint32_t *)st.child_l.ptr, (const uint32_t *)st.child_r.ptr,
                        (const uint32_t *)st.parent.ptr, (const uint32_t *)st.leaf_link.ptr, (const uint32_t *)st.leaf_count.ptr,
-                       (float4 *)st.nlo.ptr, (float4 *)st.nhi.ptr, (uint32_t *)st.flag_a.ptr, (float4 *)st.pairs.ptr);
+                       (float4 *)st.nlo.ptr, (float4 *)st.nhi.ptr, (float4 *)st.ninfo.ptr, (uint32_t *)st.flag_a.ptr, (float4 *)st.pairs.ptr,
+                       (flags & CRT_BVH_SAH_REFINE) ? (st.max_leaf < 1u ? 1u : st.max_leaf > 8u ? 8u : st.max_leaf) : 1u, st.c_isect, st.c_trav);
     HIP_TRY(hipGetLastError());
-    (void)flags;
     return true;
 }
 
 void free_build_state(BuildState &st) {
     DeviceBuffer *all[] = {&st.plo, &st.phi, &st.keys, &st.vals, &st.keys_alt, &st.vals_alt, &st.flag_a, &st.flag_b, &st.rank_a,
-                           &st.rank_b, &st.leaf_link, &st.leaf_count, &st.child_l, &st.child_r, &st.parent, &st.nlo, &st.nhi,
+                           &st.rank_b, &st.leaf_link, &st.leaf_count, &st.child_l, &st.child_r, &st.parent, &st.nlo, &st.nhi, &st.ninfo,
                            &st.scene_bounds, &st.temp, &st.pairs, &st.tri_pack, &st.sphere_pack, &st.quad_pack, &st.sphere_ids,
                            &st.quad_ids, &st.tri_ids};
     for (DeviceBuffer *b : all) if (b->ptr) { hipError_t e = hipFree(b->ptr); (void)e; b->ptr = nullptr; b->bytes = 0; }

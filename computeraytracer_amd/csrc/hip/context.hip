@@ -3,6 +3,7 @@
 // init_descriptors :1116-1237, upload_buffer :656-690, draw :1370-1498).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -230,6 +231,9 @@ int crt_bvh_build(crt_context *ctx, uint32_t flags, float *build_ms) {
     BuildInput in{(const crt_sphere *)ctx->spheres.ptr, ctx->n_spheres, (const crt_quad *)ctx->quads.ptr, ctx->n_quads,
                   (const crt_tri *)ctx->tris.ptr, ctx->n_tris};
     std::string err;
+    if (const char *e = getenv("CRT_BVH_MAX_LEAF")) ctx->build.max_leaf = (uint32_t)atoi(e);      // experiment knobs
+    if (const char *e = getenv("CRT_BVH_CI")) ctx->build.c_isect = (float)atof(e);
+    if (const char *e = getenv("CRT_BVH_CT")) ctx->build.c_trav = (float)atof(e);
     hipEvent_t e0, e1;
     CTX_HIP(hipEventCreate(&e0)); CTX_HIP(hipEventCreate(&e1));
     // warm the allocations (first build at a size allocates; the timed region below then only launches)

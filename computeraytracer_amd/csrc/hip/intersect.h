@@ -196,34 +196,56 @@ CRT_DEV void trav_begin(Traversal &tr, V3 o, V3 d) {
     tr.best_t = kInf; tr.tfar = kInf; tr.best_id = kIdMiss; tr.cur = 0; tr.sp = 0;
 }
 
-// One pair visit.  Returns false when the traversal is finished (best_t / best_id are final).
+// Stack / cursor entries are tagged: an inner node is its pair index; a leaf is
+// kLeafTag | kind << 29 | (count - 1) << 26 | first slot, so a leaf can wait in `cur` (or on the stack) until the
+// wave decides to run a leaf-test phase with many lanes at once (while-while traversal).
+constexpr uint32_t kLeafTag = 0x80000000u;
+constexpr uint32_t kMaxLeafLink = 1u << 26;
+CRT_DEV uint32_t make_entry(uint32_t link, uint32_t count_kind) {
+    if (count_kind == 0) return link;
+    return kLeafTag | ((count_kind >> 28) << 29) | (((count_kind & 0x0FFFFFFFu) - 1u) << 26) | link;
+}
+
+// Pops the next entry; false when the traversal is finished (best_t / best_id are final).
+CRT_DEV bool trav_pop(Traversal &tr, const uint32_t *stack, uint32_t stack_stride, const uint32_t *spill) {
+    if (tr.sp == 0) return false;
+    tr.sp--;
+    tr.cur = tr.sp < kLdsStack ? stack[tr.sp * stack_stride] : spill[tr.sp - kLdsStack];
+    return true;
+}
+
+// Inner phase: one pair visit (64-byte fetch, two slab tests, ordered descent).  tr.cur must be an inner entry.
 template <bool COUNT>
-CRT_DEV bool trav_step(const DeviceScene &sc, Traversal &tr, uint32_t *stack, uint32_t stack_stride, uint32_t *spill, Counts &cnt) {
+CRT_DEV bool trav_inner(const DeviceScene &sc, Traversal &tr, uint32_t *stack, uint32_t stack_stride, uint32_t *spill, Counts &cnt) {
     const float4 *p = sc.nodes + 4 * (size_t)tr.cur;
     float4 lo0 = p[0], hi0 = p[1], lo1 = p[2], hi1 = p[3];
     if (COUNT) cnt.nodes += 2;
     float tn0, tn1;
-    bool h0 = slab(lo0, hi0, tr.idir, tr.noid, tr.tfar, tn0);
-    bool h1 = slab(lo1, hi1, tr.idir, tr.noid, tr.tfar, tn1);
     uint32_t c0 = f2u(hi0.w), c1 = f2u(hi1.w);
-    if (h0 && c0 != 0) { test_leaf<COUNT>(sc, tr.o, tr.d, f2u(lo0.w), c0, tr.best_t, tr.best_id, cnt); h0 = false; }
-    if (h1 && c1 != 0) { test_leaf<COUNT>(sc, tr.o, tr.d, f2u(lo1.w), c1, tr.best_t, tr.best_id, cnt); h1 = false; }
-    tr.tfar = tr.best_t * 1.000004f;
-    uint32_t l0 = f2u(lo0.w), l1 = f2u(lo1.w);
+    bool h0 = slab(lo0, hi0, tr.idir, tr.noid, tr.tfar, tn0) && c0 != (CRT_ID_KIND_TRI << 28);   // skip the empty pad leaf
+    bool h1 = slab(lo1, hi1, tr.idir, tr.noid, tr.tfar, tn1) && c1 != (CRT_ID_KIND_TRI << 28);
+    uint32_t e0 = make_entry(f2u(lo0.w), c0), e1 = make_entry(f2u(lo1.w), c1);
     if (h0 && h1) {
         bool first0 = tn0 <= tn1;
-        uint32_t nearc = first0 ? l0 : l1, farc = first0 ? l1 : l0;
+        uint32_t nearc = first0 ? e0 : e1, farc = first0 ? e1 : e0;
         if (tr.sp < kLdsStack) stack[tr.sp * stack_stride] = farc; else if (tr.sp < kLdsStack + kSpillStack) spill[tr.sp - kLdsStack] = farc;
         tr.sp++;
         tr.cur = nearc;
-    } else if (h0) tr.cur = l0;
-    else if (h1) tr.cur = l1;
-    else {
-        if (tr.sp == 0) return false;
-        tr.sp--;
-        tr.cur = tr.sp < kLdsStack ? stack[tr.sp * stack_stride] : spill[tr.sp - kLdsStack];
+        return true;
     }
-    return true;
+    if (h0) { tr.cur = e0; return true; }
+    if (h1) { tr.cur = e1; return true; }
+    return trav_pop(tr, stack, stack_stride, spill);
+}
+
+// Leaf phase: test the primitives of the leaf entry in tr.cur, then pop.
+template <bool COUNT>
+CRT_DEV bool trav_leaf(const DeviceScene &sc, Traversal &tr, const uint32_t *stack, uint32_t stack_stride, const uint32_t *spill, Counts &cnt) {
+    const uint32_t e = tr.cur;
+    const uint32_t kind = (e >> 29) & 3u, n = ((e >> 26) & 7u) + 1u, first = e & (kMaxLeafLink - 1u);
+    test_leaf<COUNT>(sc, tr.o, tr.d, first, (kind << 28) | n, tr.best_t, tr.best_id, cnt);
+    tr.tfar = tr.best_t * 1.000004f;       // relative pad (2^-18) on the far bound
+    return trav_pop(tr, stack, stack_stride, spill);
 }
 
 // The shader's HitRecord (compute.comp:195-203), rebuilt for the winning primitive from the

@@ -168,6 +168,7 @@ struct WfQueues {
     uint32_t n_shards;                     // sub-queues in use (<= kShards)
     uint32_t precheck;                     // experiment knob: load the cursor before the fetch atomic
     uint32_t refill;                       // idle lanes that trigger a refill
+    uint32_t leaf_lanes;                   // lanes waiting at a leaf that trigger a leaf-test phase
 };
 
 constexpr uint32_t kDeadPixel = 0xFFFFFFFFu;   // queue entry of a lane outside the rendered grid (ragged sizes only)
@@ -300,14 +301,23 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
             if (drained) break;
             continue;
         }
-        if (busy) {
-            Counts cnt = {0, 0};
-            if (!trav_step<COUNT>(sc, tr, stack, 256, spill, cnt)) {
-                q.hit[slot] = make_uint2(f2u(tr.best_t), tr.best_id);
-                busy = false;
-            }
-            if (COUNT) { nodes += cnt.nodes; prims += cnt.prims; }
+        // while-while: lanes whose cursor is a leaf wait until enough of them have one (or nobody can descend),
+        // then the wave runs one leaf-test phase; otherwise the others do one inner step
+        const bool at_leaf = busy && (tr.cur & kLeafTag) != 0;
+        const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
+        const bool any_inner = __ballot(busy && !at_leaf) != 0;
+        Counts cnt = {0, 0};
+        bool more = true;
+        if (n_leaf >= q.leaf_lanes || !any_inner) {
+            if (at_leaf) more = trav_leaf<COUNT>(sc, tr, stack, 256, spill, cnt);
+        } else if (busy && !at_leaf) {
+            more = trav_inner<COUNT>(sc, tr, stack, 256, spill, cnt);
         }
+        if (!more) {
+            q.hit[slot] = make_uint2(f2u(tr.best_t), tr.best_id);
+            busy = false;
+        }
+        if (COUNT) { nodes += cnt.nodes; prims += cnt.prims; }
     }
     if (COUNT) {
         nodes = wave_sum(nodes); prims = wave_sum(prims);
@@ -387,6 +397,7 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     Frame f = make_frame(fs, params);
     if (f.n_tiles == 0) return true;
     if (f.max_bounces > kMaxBounces) { err = "wavefront tracer supports at most 16 bounces"; return false; }
+    if (sch.n_pairs + 1 >= kMaxLeafLink) { err = "wavefront tracer supports at most 2^26 primitives"; return false; }
     WfQueues q;
     static const uint32_t env_shards = [] { const char *e = getenv("CRT_WF_SHARDS"); int v = e ? atoi(e) : 16;
                                             return (uint32_t)((v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? v : 16); }();
@@ -395,6 +406,8 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     q.precheck = env_precheck;
     static const uint32_t env_refill = [] { const char *e = getenv("CRT_WF_REFILL"); int v = e ? atoi(e) : (int)kRefillLanes; return (uint32_t)(v < 1 ? 1 : v > 64 ? 64 : v); }();
     q.refill = env_refill;
+    static const uint32_t env_leaf = [] { const char *e = getenv("CRT_WF_LEAF_LANES"); int v = e ? atoi(e) : 16; return (uint32_t)(v < 1 ? 1 : v > 64 ? 64 : v); }();
+    q.leaf_lanes = env_leaf;
     q.tiles_per_shard = (f.n_tiles + q.n_shards - 1) / q.n_shards;
     q.shard_cap = q.tiles_per_shard * 64;
     const uint32_t cap = q.shard_cap * q.n_shards;

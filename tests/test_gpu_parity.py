@@ -25,10 +25,10 @@ def _params(scene, n):
     return [scene.params_for(i + 1, seeds[i]) for i in range(n)], seeds
 
 
-def _gpu_render(ctx, scene, w, h, n_iter, **cfg):
+def _gpu_render(ctx, scene, w, h, n_iter, bvh=abi.BVH_LBVH, **cfg):
     ctx.configure(w, h, **cfg)
     ctx.upload(scene)
-    ctx.build()
+    ctx.build(bvh)
     ps, seeds = _params(scene, n_iter)
     ctx.render(ps[0], 1, seeds)
     ctx.sync()
@@ -187,3 +187,20 @@ def test_stats_count_hit_world_calls(ctx):
     _, _, cnt = orc.render(scene, ps, 96, 56, flags=orc.TRAVERSE_FAST)
     assert st.rays == cnt.rays and st.paths == cnt.paths == 2 * 96 * 56
     assert st.node_visits > st.rays and st.prim_tests > 0 and st.last_render_ms > 0
+
+
+@pytest.mark.parametrize("name,w,h,n_iter", CASES + [("cirno", 96, 60, 2)])
+def test_sah_collapsed_bvh_bit_exact(ctx, golden_dir, name, w, h, n_iter):
+    scene = abi.builtin_scene(name, w, h, golden_dir)
+    img, ids, ps = _gpu_render(ctx, scene, w, h, n_iter, bvh=abi.BVH_SAH_REFINE, tracer=abi.TRACER_WAVEFRONT)
+    ref_img, ref_ids, _ = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_FAST)
+    assert np.array_equal(ids, ref_ids)
+    assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32))
+    nodes, sid, qid, tid = ctx.bvh()
+    leaves = nodes[nodes["count"] != 0]
+    sizes = leaves["count"] & 0x0FFFFFFF
+    assert sizes.max() <= 4
+    # the oracle walking the collapsed device tree agrees with brute force
+    a, i, _ = orc.render(scene, ps[:1], w, h, flags=orc.TRAVERSE_BUILD, build_bvh=(nodes, sid, qid, tid))
+    b, j, _ = orc.render(scene, ps[:1], w, h, flags=orc.TRAVERSE_FAST)
+    assert np.array_equal(i, j) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
