@@ -116,6 +116,7 @@ def main():
     run(1, args.warmup)
     ctx.sync()
     ctx.stats_reset()
+    ctx.set_kernel_timing(True)       # HIP events around every k_wf_extend launch, on the stream it is launched on
 
     def barrier():
         if dist is not None:
@@ -154,12 +155,20 @@ def main():
 
     if rank == 0:
         mrays = rays / elapsed / 1e6
+        # bytes/ray of the whole pipeline = 32 V + 48 T + 128 (queue entry written + read) + 32 / D (accumulation)
         bytes_per_ray = 32.0 * V + 48.0 * T + (128.0 if tracer == abi.TRACER_WAVEFRONT else 0.0) + 32.0 / D
-        # dominant kernel: the tracer.  algorithmic bytes per launch = rays per launch x bytes/ray (rank 0's share)
         rank_rays = float(st.rays)
-        launch_ms = kernel_ms / args.steps if not rebuild else kernel_ms
-        launch_rays = rank_rays / args.steps
-        achieved = launch_rays * bytes_per_ray / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        if tracer == abi.TRACER_WAVEFRONT and st.last_extend_launches:
+            # dominant kernel k_wf_extend: of that figure it moves 32 V + 48 T + 32 (ray read) + 8 (hit record written)
+            kernel_name, kernel_bytes_per_ray = "k_wf_extend", 32.0 * V + 48.0 * T + 40.0
+            n_launches = float(st.last_extend_launches) if not rebuild else float(st.last_extend_launches) * args.steps
+            launch_ms = st.last_extend_ms / st.last_extend_launches
+        else:
+            kernel_name, kernel_bytes_per_ray = "k_megakernel", bytes_per_ray
+            n_launches = float(args.steps)
+            launch_ms = kernel_ms / args.steps if not rebuild else kernel_ms
+        launch_rays = rank_rays / n_launches
+        achieved = launch_rays * kernel_bytes_per_ray / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         line = {
             "metric": "Mrays/s (whole node) lost_empire 4K 256spp; BVH build ms; RMSE vs ref",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,8 +181,9 @@ def main():
                        "rays_per_path": round(D, 3), "nodes_per_ray": round(V, 2), "prim_tests_per_ray": round(T, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "k_megakernel" if tracer == abi.TRACER_MEGAKERNEL else "k_wf_extend",
-                         "bytes_per_ray": round(bytes_per_ray, 1), "launch_ms": round(launch_ms, 4)},
+                         "kernel": kernel_name, "kernel_bytes_per_ray": round(kernel_bytes_per_ray, 1),
+                         "pipeline_bytes_per_ray": round(bytes_per_ray, 1), "launch_ms": round(launch_ms, 4),
+                         "launches": int(n_launches), "rays_per_launch": round(launch_rays)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene)

@@ -62,7 +62,8 @@ class Config(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64),
-                ("last_render_ms", C.c_double), ("last_build_ms", C.c_double)]
+                ("last_render_ms", C.c_double), ("last_build_ms", C.c_double), ("last_extend_ms", C.c_double),
+                ("last_extend_launches", C.c_uint64)]
 
 
 class CrtError(RuntimeError):
@@ -97,6 +98,7 @@ def _load():
         "crt_stats_read": (i32, [vp, P(Stats)]),
         "crt_stats_reset": (i32, [vp]),
         "crt_set_instrumented": (i32, [vp, i32]),
+        "crt_set_kernel_timing": (i32, [vp, i32]),
         "crt_bvh_read": (i32, [vp, vp, P(u32), vp, vp, vp]),
         "crt_camera_init": (None, [vp, P(f32), P(f32), f32, f32, f32, f32]),
         "crt_frame_seeds": (None, [u32, u32, vp]),
@@ -337,6 +339,9 @@ class Context:
 
     def set_instrumented(self, on):
         self._check(lib.crt_set_instrumented(self._h, int(bool(on))), "crt_set_instrumented")
+
+    def set_kernel_timing(self, on):
+        self._check(lib.crt_set_kernel_timing(self._h, int(bool(on))), "crt_set_kernel_timing")
 
     def bvh(self):
         """(nodes, sphere_ids, quad_ids, tri_ids): ids are full primitive IDs (kind << 30 | index)."""

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "crt/types.h"
 
@@ -57,6 +58,9 @@ struct DeviceStats { unsigned long long rays, paths, node_visits, prim_tests; };
 struct WavefrontState {
     uint32_t capacity = 0;           // paths the queues can hold
     DeviceBuffer ray_o[2], ray_d[2], thr[2], emi[2], hit, counters, pass;
+    bool time_kernels = false;
+    std::vector<hipEvent_t> ev;      // start/stop pairs around extend launches
+    size_t ev_used = 0;
 };
 
 bool launch_megakernel(hipStream_t stream, const DeviceSceneHost &sc, const FrameSetup &fs, const crt_scene_params &params,

@@ -30,7 +30,8 @@ struct crt_context {
     uint32_t grid_w = 0, grid_h = 0, n_local_bands = 0, local_rows = 0;
     WavefrontState wf;
     int instrumented = 0;
-    double last_render_ms = 0.0, last_build_ms = 0.0;
+    double last_render_ms = 0.0, last_build_ms = 0.0, last_extend_ms = 0.0;
+    uint64_t last_extend_launches = 0;
 };
 
 namespace {
@@ -99,6 +100,13 @@ int finish_timing(crt_context *ctx) {
     CTX_HIP(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
     ctx->last_render_ms = ms;
     ctx->timing_pending = false;
+    ctx->last_extend_ms = 0.0; ctx->last_extend_launches = ctx->wf.ev_used / 2;
+    for (size_t i = 0; i + 1 < ctx->wf.ev_used; i += 2) {
+        float e = 0.0f;
+        CTX_HIP(hipEventElapsedTime(&e, ctx->wf.ev[i], ctx->wf.ev[i + 1]));
+        ctx->last_extend_ms += e;
+    }
+    ctx->wf.ev_used = 0;
     return CRT_OK;
 }
 
@@ -385,6 +393,7 @@ int crt_stats_read(crt_context *ctx, crt_stats *out) {
     CTX_HIP(hipMemcpy(&ds, ctx->stats.ptr, sizeof ds, hipMemcpyDeviceToHost));
     out->rays = ds.rays; out->paths = ds.paths; out->node_visits = ds.node_visits; out->prim_tests = ds.prim_tests;
     out->last_render_ms = ctx->last_render_ms; out->last_build_ms = ctx->last_build_ms;
+    out->last_extend_ms = ctx->last_extend_ms; out->last_extend_launches = ctx->last_extend_launches;
     return CRT_OK;
 }
 
@@ -397,6 +406,12 @@ int crt_stats_reset(crt_context *ctx) {
 int crt_set_instrumented(crt_context *ctx, int on) {
     if (!ctx) return CRT_ERR_INVALID;
     ctx->instrumented = on ? 1 : 0;
+    return CRT_OK;
+}
+
+int crt_set_kernel_timing(crt_context *ctx, int on) {
+    if (!ctx) return CRT_ERR_INVALID;
+    ctx->wf.time_kernels = on != 0;
     return CRT_OK;
 }
 

@@ -447,8 +447,13 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     else hipLaunchKernelGGL((k_wf_generate<0>), gen_grid, block, 0, stream, f, q);
     for (uint32_t b = 0; b < f.max_bounces; b++) {
         const unsigned long long dead_b = b == 0 ? dead : 0ull;
+        if (wf.time_kernels) {
+            if (wf.ev_used + 2 > wf.ev.size()) { hipEvent_t a, c; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&c)); wf.ev.push_back(a); wf.ev.push_back(c); }
+            HIP_TRY(hipEventRecord(wf.ev[wf.ev_used], stream));
+        }
         if (fs.instrumented) hipLaunchKernelGGL((k_wf_extend<true>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
         else hipLaunchKernelGGL((k_wf_extend<false>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
+        if (wf.time_kernels) { HIP_TRY(hipEventRecord(wf.ev[wf.ev_used + 1], stream)); wf.ev_used += 2; }
         if (pcg) hipLaunchKernelGGL((k_wf_shade<1>), pgrid, block, 0, stream, sc, f, q, b, acc, hit_ids);
         else hipLaunchKernelGGL((k_wf_shade<0>), pgrid, block, 0, stream, sc, f, q, b, acc, hit_ids);
     }
@@ -460,6 +465,8 @@ void free_wavefront(WavefrontState &wf) {
     DeviceBuffer *all[] = {&wf.ray_o[0], &wf.ray_o[1], &wf.ray_d[0], &wf.ray_d[1], &wf.thr[0], &wf.thr[1], &wf.emi[0], &wf.emi[1],
                            &wf.hit, &wf.counters, &wf.pass};
     for (DeviceBuffer *b : all) if (b->ptr) { hipError_t e = hipFree(b->ptr); (void)e; b->ptr = nullptr; b->bytes = 0; }
+    for (hipEvent_t e : wf.ev) { hipError_t r = hipEventDestroy(e); (void)r; }
+    wf.ev.clear(); wf.ev_used = 0;
     wf.capacity = 0;
 }
 

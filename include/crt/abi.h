@@ -114,6 +114,9 @@ int crt_stats_reset(crt_context *ctx);
 /* Makes the next dispatches count node visits and primitive tests too
  * (slower; used to measure the V and T terms of the bytes-per-ray model). */
 int crt_set_instrumented(crt_context *ctx, int on);
+/* Brackets every k_wf_extend launch (the dominant kernel) with HIP events on the context's stream so that
+ * crt_stats.last_extend_ms reports its device time separately (bench.py's roofline figure). */
+int crt_set_kernel_timing(crt_context *ctx, int on);
 
 /* Read back the build's BVH for cross-checks: nodes (pair layout, see
  * crt_bvh_node) and, per kind, the input ID of each sorted primitive slot.

@@ -175,6 +175,9 @@ typedef struct crt_stats {
     uint64_t prim_tests;      /* only counted by instrumented launches */
     double   last_render_ms;  /* device time of the last crt_dispatch/crt_render */
     double   last_build_ms;   /* device time of the last crt_bvh_build */
+    double   last_extend_ms;  /* summed device time of the k_wf_extend launches of the last crt_dispatch/crt_render
+                                 (only with crt_set_kernel_timing on and the wavefront tracer; else 0) */
+    uint64_t last_extend_launches;
 } crt_stats;
 
 #ifdef __cplusplus

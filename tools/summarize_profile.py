@@ -18,7 +18,22 @@ def short(name):
     return name.replace("void ", "")
 
 
-rows = list(csv.DictReader(open(sys.argv[1])))
+def load(path):
+    """kernel_stats.csv rows, or the same aggregate computed from a rocpd results .db (rocprofv3's default output)."""
+    if not path.endswith(".db"):
+        return list(csv.DictReader(open(path)))
+    import sqlite3
+    con = sqlite3.connect(path)
+    per = {}
+    for name, dur in con.execute("select name, duration from kernels"):
+        a = per.setdefault(name, [0, 0, 1 << 62, 0])
+        a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)
+    total = sum(a[1] for a in per.values()) or 1
+    return [{"Name": k, "Calls": a[0], "TotalDurationNs": a[1], "MinNs": a[2], "MaxNs": a[3], "Percentage": 100.0 * a[1] / total}
+            for k, a in per.items()]
+
+
+rows = load(sys.argv[1])
 print(f"# rocprofv3 --kernel-trace --stats\n\ncommand: `{sys.argv[2] if len(sys.argv) > 2 else ''}`\n")
 print("| kernel | calls | total ms | avg us | % | min us | max us |")
 print("|---|---:|---:|---:|---:|---:|---:|")
