@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--workload", default="lost_empire_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--tracer", default=os.environ.get("CRT_TRACER", "wavefront"), choices=["megakernel", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bvh", default=os.environ.get("CRT_BVH", "lbvh"), choices=["lbvh", "sah"])
+    ap.add_argument("--bvh", default=os.environ.get("CRT_BVH", "lbvh"), choices=["lbvh", "sah", "collapse"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,7 +88,7 @@ def main():
     ctx = abi.Context(local_rank)
     ctx.configure(W, H, tracer=tracer, band_rank=rank, band_world=world)
     ctx.upload(scene)
-    bvh_flags = abi.BVH_SAH_REFINE if args.bvh == "sah" else abi.BVH_LBVH
+    bvh_flags = {"lbvh": abi.BVH_LBVH, "sah": abi.BVH_SAH_REFINE, "collapse": abi.BVH_LEAF_COLLAPSE}[args.bvh]
     build_ms = ctx.build(bvh_flags)
     build_ms = ctx.build(bvh_flags)   # second build: allocations are warm, this is the device time of the build alone
     seeds = abi.frame_seeds(0, args.warmup + args.steps + 1)

@@ -18,7 +18,7 @@ KIND_SPHERE, KIND_QUAD, KIND_TRI = 0, 1, 2
 RNG_REF, RNG_PCG = 0, 1
 TRACER_MEGAKERNEL, TRACER_WAVEFRONT = 0, 1
 FLAG_FULL_IMAGE = 1
-BVH_LBVH, BVH_SAH_REFINE = 0, 1
+BVH_LBVH, BVH_SAH_REFINE, BVH_LEAF_COLLAPSE = 0, 1, 2
 
 # numpy views of the POD layouts in include/crt/types.h
 sphere_dtype = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("pad0", "<f4", 3), ("materialIndex", "<u4")])
@@ -99,6 +99,7 @@ def _load():
         "crt_stats_reset": (i32, [vp]),
         "crt_set_instrumented": (i32, [vp, i32]),
         "crt_set_kernel_timing": (i32, [vp, i32]),
+        "crt_loop_counters_read": (i32, [vp, vp, u32]),
         "crt_bvh_read": (i32, [vp, vp, P(u32), vp, vp, vp]),
         "crt_camera_init": (None, [vp, P(f32), P(f32), f32, f32, f32, f32]),
         "crt_frame_seeds": (None, [u32, u32, vp]),
@@ -339,6 +340,11 @@ class Context:
 
     def set_instrumented(self, on):
         self._check(lib.crt_set_instrumented(self._h, int(bool(on))), "crt_set_instrumented")
+
+    def loop_counters(self):
+        out = np.zeros((16, 6), dtype=np.uint64)
+        self._check(lib.crt_loop_counters_read(self._h, _ptr(out), 96), "crt_loop_counters_read")
+        return out
 
     def set_kernel_timing(self, on):
         self._check(lib.crt_set_kernel_timing(self._h, int(bool(on))), "crt_set_kernel_timing")

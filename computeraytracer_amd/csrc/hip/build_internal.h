@@ -25,11 +25,16 @@ struct BuildState {
     DeviceBuffer child_l, child_r, parent, nlo, nhi, ninfo, scene_bounds, temp;
     // SAH leaf-collapse parameters (CRT_BVH_SAH_REFINE)
     uint32_t max_leaf = 4; float c_isect = 1.0f, c_trav = 1.0f;
+    // SAH refinement (bvh_sah.hip): LBVH node ranges, tier tables, group descriptors, final primitive order
+    DeviceBuffer range_lo, range_hi, sah_flag, sah_ipos[2], sah_starts, sah_desc, perm;
+    uint32_t sah_tiers = 0;
     // results (what traversal reads)
     DeviceBuffer pairs, tri_pack, sphere_pack, quad_pack, sphere_ids, quad_ids, tri_ids;
 };
 
 bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildState &st, std::string &err);
+bool build_sah(hipStream_t stream, const BuildInput &in, BuildState &st, const uint32_t *vals, std::string &err);
+bool patch_sah_links(hipStream_t stream, BuildState &st, std::string &err);
 bool animate_tris(hipStream_t stream, uint32_t n, const crt_tri *rest, crt_tri *out, float frame, float amplitude, std::string &err);
 void free_build_state(BuildState &st);
 
@@ -53,7 +58,12 @@ struct FrameSetup {
     uint32_t instrumented;
 };
 
-struct DeviceStats { unsigned long long rays, paths, node_visits, prim_tests; };
+struct DeviceStats {
+    unsigned long long rays, paths, node_visits, prim_tests;
+    // instrumented k_wf_extend only, per bounce: loop iterations, inner-phase iterations, lanes stepping in them,
+    // leaf-phase iterations, lanes testing in them, iterations that refilled lanes
+    unsigned long long loop[16][6];
+};
 
 struct WavefrontState {
     uint32_t capacity = 0;           // paths the queues can hold

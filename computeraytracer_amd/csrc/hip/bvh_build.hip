@@ -23,12 +23,9 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "build_internal.h"
+#include "bvh_common.h"
 
 namespace crt {
-
-// Order-preserving float <-> uint mapping for atomic min/max.
-__device__ __forceinline__ uint32_t enc_f(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
-__device__ __forceinline__ float dec_f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
 
 __global__ void k_init_bounds(uint32_t *b) {
     if (threadIdx.x < 3) b[threadIdx.x] = 0xFFFFFFFFu;       // min
@@ -166,7 +163,8 @@ __device__ __forceinline__ int delta(const uint32_t *keys, int n, int i, int j) 
 }
 
 // Node numbering: inner i in [0, n-2], leaf j -> (n - 1) + j.  parent[] is indexed by that numbering.
-__global__ void k_hierarchy(int n, const uint32_t *keys, uint32_t *child_l, uint32_t *child_r, uint32_t *parent) {
+__global__ void k_hierarchy(int n, const uint32_t *keys, uint32_t *child_l, uint32_t *child_r, uint32_t *parent,
+                            uint32_t *range_lo, uint32_t *range_hi) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
@@ -189,6 +187,7 @@ __global__ void k_hierarchy(int n, const uint32_t *keys, uint32_t *child_l, uint
     child_l[i] = left; child_r[i] = right;
     parent[left] = (uint32_t)i; parent[right] = (uint32_t)i;
     if (i == 0) parent[0] = 0xFFFFFFFFu;
+    if (range_lo) { range_lo[i] = (uint32_t)min(i, j); range_hi[i] = (uint32_t)max(i, j); }     // sorted positions the node covers
 }
 
 // Per-subtree summary carried up by the refit: primitive count, SAH cost, kind (or kMixed), first leaf of its
@@ -202,10 +201,6 @@ __device__ __forceinline__ float4 sub_pack(Sub s) {
 }
 __device__ __forceinline__ Sub sub_unpack(float4 v) {
     Sub s; s.count = __float_as_uint(v.x); s.cost = v.y; s.kind_flags = __float_as_uint(v.z); s.first = __float_as_uint(v.w); return s;
-}
-__device__ __forceinline__ float half_area(float4 lo, float4 hi) {
-    float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
-    return dx * dy + dy * dz + dx * dz;
 }
 
 // Child record inside its parent's pair: an inner child links to its own pair, a leaf (single primitive or a
@@ -361,9 +356,24 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     size_t tb = st.temp.bytes;
     HIP_TRY(rocprim::radix_sort_pairs(st.temp.ptr, tb, dkeys, dvals, n, 0, 30, stream));
     const uint32_t *keys = dkeys.current(), *vals = dvals.current();
-    st.sorted_vals = vals;
 
-    hipLaunchKernelGGL(k_kind_flags, dim3(blocks), dim3(256), 0, stream, n, vals, in.n_spheres, in.n_quads,
+    // SAH refinement: the Karras hierarchy only clusters; bvh_sah.hip rebuilds the topology and reorders the primitives
+    const bool sah = (flags & CRT_BVH_SAH_REFINE) != 0 && n >= 2;
+    const uint32_t *order = vals;
+    if (n >= 2) {
+        if (sah && (!ensure(st.range_lo, (size_t)n * 4, err) || !ensure(st.range_hi, (size_t)n * 4, err))) return false;
+        hipLaunchKernelGGL(k_hierarchy, dim3((n - 1 + 255) / 256), dim3(256), 0, stream, (int)n, keys, (uint32_t *)st.child_l.ptr,
+                           (uint32_t *)st.child_r.ptr, (uint32_t *)st.parent.ptr, sah ? (uint32_t *)st.range_lo.ptr : nullptr,
+                           sah ? (uint32_t *)st.range_hi.ptr : nullptr);
+        HIP_TRY(hipGetLastError());
+    }
+    if (sah) {
+        if (!build_sah(stream, in, st, vals, err)) return false;
+        order = (const uint32_t *)st.perm.ptr;
+    }
+    st.sorted_vals = order;
+
+    hipLaunchKernelGGL(k_kind_flags, dim3(blocks), dim3(256), 0, stream, n, order, in.n_spheres, in.n_quads,
                        (uint32_t *)st.flag_a.ptr, (uint32_t *)st.flag_b.ptr);
     tb = st.temp.bytes;
     HIP_TRY(rocprim::exclusive_scan(st.temp.ptr, tb, (uint32_t *)st.flag_a.ptr, (uint32_t *)st.rank_a.ptr, 0u, n,
@@ -371,26 +381,25 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     tb = st.temp.bytes;
     HIP_TRY(rocprim::exclusive_scan(st.temp.ptr, tb, (uint32_t *)st.flag_b.ptr, (uint32_t *)st.rank_b.ptr, 0u, n,
                                     rocprim::plus<uint32_t>(), stream));
-    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, stream, in, n, vals, (const uint32_t *)st.rank_a.ptr,
+    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, stream, in, n, order, (const uint32_t *)st.rank_a.ptr,
                        (const uint32_t *)st.rank_b.ptr, (float4 *)st.tri_pack.ptr, (float4 *)st.sphere_pack.ptr,
                        (float4 *)st.quad_pack.ptr, (uint32_t *)st.sphere_ids.ptr, (uint32_t *)st.quad_ids.ptr,
                        (uint32_t *)st.tri_ids.ptr, (uint32_t *)st.leaf_link.ptr, (uint32_t *)st.leaf_count.ptr);
     HIP_TRY(hipGetLastError());
 
     if (n == 1) {
-        hipLaunchKernelGGL(k_single_pair, dim3(1), dim3(64), 0, stream, vals, (const float4 *)st.plo.ptr, (const float4 *)st.phi.ptr,
+        hipLaunchKernelGGL(k_single_pair, dim3(1), dim3(64), 0, stream, order, (const float4 *)st.plo.ptr, (const float4 *)st.phi.ptr,
                            (const uint32_t *)st.leaf_link.ptr, (const uint32_t *)st.leaf_count.ptr, (float4 *)st.pairs.ptr);
         HIP_TRY(hipGetLastError());
         return true;
     }
-    hipLaunchKernelGGL(k_hierarchy, dim3((n - 1 + 255) / 256), dim3(256), 0, stream, (int)n, keys, (uint32_t *)st.child_l.ptr,
-                       (uint32_t *)st.child_r.ptr, (uint32_t *)st.parent.ptr);
+    if (sah) return patch_sah_links(stream, st, err);
     HIP_TRY(hipMemsetAsync(st.flag_a.ptr, 0, (size_t)n * 4, stream));
     hipLaunchKernelGGL(k_refit_emit, dim3(blocks), dim3(256), 0, stream, (int)n, vals, (const float4 *)st.plo.ptr,
                        (const float4 *)st.phi.ptr, (const uint32_t *)st.child_l.ptr, (const uint32_t *)st.child_r.ptr,
                        (const uint32_t *)st.parent.ptr, (const uint32_t *)st.leaf_link.ptr, (const uint32_t *)st.leaf_count.ptr,
                        (float4 *)st.nlo.ptr, (float4 *)st.nhi.ptr, (float4 *)st.ninfo.ptr, (uint32_t *)st.flag_a.ptr, (float4 *)st.pairs.ptr,
-                       (flags & CRT_BVH_SAH_REFINE) ? (st.max_leaf < 1u ? 1u : st.max_leaf > 8u ? 8u : st.max_leaf) : 1u, st.c_isect, st.c_trav);
+                       (flags & CRT_BVH_LEAF_COLLAPSE) ? (st.max_leaf < 1u ? 1u : st.max_leaf > 8u ? 8u : st.max_leaf) : 1u, st.c_isect, st.c_trav);
     HIP_TRY(hipGetLastError());
     return true;
 }
@@ -398,7 +407,8 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
 void free_build_state(BuildState &st) {
     DeviceBuffer *all[] = {&st.plo, &st.phi, &st.keys, &st.vals, &st.keys_alt, &st.vals_alt, &st.flag_a, &st.flag_b, &st.rank_a,
                            &st.rank_b, &st.leaf_link, &st.leaf_count, &st.child_l, &st.child_r, &st.parent, &st.nlo, &st.nhi, &st.ninfo,
-                           &st.scene_bounds, &st.temp, &st.pairs, &st.tri_pack, &st.sphere_pack, &st.quad_pack, &st.sphere_ids,
+                           &st.scene_bounds, &st.temp, &st.range_lo, &st.range_hi, &st.sah_flag, &st.sah_ipos[0],
+                           &st.sah_ipos[1], &st.sah_starts, &st.sah_desc, &st.perm, &st.pairs, &st.tri_pack, &st.sphere_pack, &st.quad_pack, &st.sphere_ids,
                            &st.quad_ids, &st.tri_ids};
     for (DeviceBuffer *b : all) if (b->ptr) { hipError_t e = hipFree(b->ptr); (void)e; b->ptr = nullptr; b->bytes = 0; }
 }

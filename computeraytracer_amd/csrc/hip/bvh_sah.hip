@@ -1,0 +1,454 @@
+// bvh_sah.hip -- SAH refinement of the Morton LBVH (CRT_BVH_SAH_REFINE).
+//
+// The reference builds its tree with a full-sweep surface-area heuristic on the host
+// (raytracing/src/bounding_volume_hierarchy.cpp:26-79, row B1 of SURVEY.md section 8(a)).  This is the device
+// counterpart: the LBVH (Morton sort + Karras hierarchy, bvh_build.hip) supplies a spatial order and a
+// clustering, and the tree topology is then rebuilt top-down with the SAH:
+//
+//   tiers   Level-0 items are the primitives in Morton order.  The level-(l+1) items ("groups") are the maximal
+//           LBVH subtrees holding at most kGroup level-l items; a group is a contiguous run of items and, being
+//           an LBVH subtree, an aligned cell of the Morton grid.  Tiers are added until one group holds everything.
+//   groups  One 256-thread workgroup rebuilds one group entirely in LDS (boxes 24 KiB + index permutation):
+//             nodes with more than 64 items: all four waves, 16-bin SAH on three axes (LDS atomic min/max on
+//               order-preserving keys), stable partition by ballot + prefix counts;
+//             nodes with at most 64 items: one wave per subtree, exact sweep SAH (every item's centroid is a
+//               candidate plane on every axis, item boxes broadcast with v_readlane), partition by ballot.
+//           Level-0 groups may close a subtree of one kind as a multi-primitive leaf when the SAH says so.
+//   layout  A subtree over k items owns k - 1 consecutive 64-byte sibling pairs, itself first, then its left
+//           subtree, then its right one (depth-first order), so no allocation counter is needed and a group's
+//           pairs start at a base computed from the tier sizes.  Pair 0 is the root.
+// Everything is deterministic (integer atomics on encoded floats, stable partitions).
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include <rocprim/device/device_scan.hpp>
+
+#include "build_internal.h"
+#include "bvh_common.h"
+
+namespace crt {
+
+constexpr uint32_t kGroup = 1024;       // items per group
+constexpr uint32_t kWaveNode = 64;      // nodes up to this size are built by one wave
+constexpr int kBins = 16;
+constexpr uint32_t kEntRoot = 1u << 23;
+constexpr float kFInf = __builtin_huge_valf();
+
+// ---- tiers ---------------------------------------------------------------------------------------------------
+// Node numbering of the LBVH: inner i in [0, n-2], leaf j -> n - 1 + j.  ipos[s] = 1-based index of the level-l
+// item that holds sorted position s (null: level 0, every position is its own item).
+__device__ __forceinline__ uint32_t items_under(uint32_t node, uint32_t n, const uint32_t *range_lo, const uint32_t *range_hi,
+                                                const uint32_t *ipos, uint32_t &first) {
+    uint32_t f, l;
+    if (node < n - 1) { f = range_lo[node]; l = range_hi[node]; } else { f = l = node - (n - 1); }
+    first = f;
+    return ipos ? ipos[l] - ipos[f] + 1u : l - f + 1u;
+}
+
+__global__ void k_sah_flags(uint32_t n, uint32_t max_items, const uint32_t *range_lo, const uint32_t *range_hi,
+                            const uint32_t *parent, const uint32_t *ipos, uint32_t *flag) {
+    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= 2 * n - 1) return;
+    uint32_t first, pf;
+    if (items_under(x, n, range_lo, range_hi, ipos, first) > max_items) return;
+    uint32_t p = parent[x];
+    if (p != 0xFFFFFFFFu && items_under(p, n, range_lo, range_hi, ipos, pf) <= max_items) return;
+    flag[first] = 1u;      // x is a maximal subtree of at most max_items items: a group starts here
+}
+
+__global__ void k_sah_starts(uint32_t n, const uint32_t *flag, const uint32_t *ipos_next, const uint32_t *ipos, uint32_t *starts) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n || !flag[s]) return;
+    starts[ipos_next[s] - 1u] = ipos ? ipos[s] - 1u : s;      // first level-l item of the group
+}
+
+// ---- one group ------------------------------------------------------------------------------------------------
+struct SahGroupArgs {
+    const uint32_t *starts; uint32_t n_groups, n_items, pair_base, level0;
+    const uint32_t *vals; const float4 *plo, *phi; uint32_t n_spheres, n_quads;   // level 0: items are primitives
+    const float4 *desc_in;     // upper tiers: two float4 per item, in the layout of half a sibling pair
+    float4 *desc_out;          // two float4 per group (null for the last tier)
+    float4 *pairs;
+    uint32_t *perm;            // level 0: final primitive order
+    uint32_t max_leaf; float c_isect, c_trav;
+};
+
+struct SahLds {
+    float box[6][kGroup];            // lo.xyz, hi.xyz of the group's items
+    uint16_t idx[kGroup], tmp[kGroup];
+    uint8_t kind[kGroup];
+    uint2 ent[2 * kGroup];           // work entries: stack of large nodes from the bottom, list of small subtrees from the top
+    uint2 wstack[4][kWaveNode + 2];
+    uint32_t bins[3 * kBins * 7];    // per axis and bin: count, lo.xyz, hi.xyz (encoded)
+    uint32_t red[12];                // centroid min, centroid max, box min, box max (encoded)
+    uint32_t wave_cnt[4];
+    uint32_t top, n_small, cursor, best_axis, best_plane, best_nl;
+};
+
+// work entry: x = a | b << 16 (item range [a, b) of the permutation), y = p | pp << 11 | side << 22 | root << 23
+// (p = first pair owned by the subtree, pp/side = where its descriptor goes: half `side` of pair pp).
+__device__ __forceinline__ uint2 make_ent(uint32_t a, uint32_t b, uint32_t p, uint32_t pp, uint32_t side) {
+    return make_uint2(a | (b << 16), p | (pp << 11) | (side << 22));
+}
+
+__device__ __forceinline__ void put_desc(const SahGroupArgs &g, uint32_t group, uint32_t pair_base, uint32_t y,
+                                         const float lo[3], const float hi[3], uint32_t link, uint32_t count) {
+    float4 *dst;
+    if (y & kEntRoot) { if (!g.desc_out) return; dst = g.desc_out + 2 * (size_t)group; }
+    else dst = g.pairs + 4 * (size_t)(pair_base + ((y >> 11) & 0x7FFu)) + 2 * ((y >> 22) & 1u);
+    dst[0] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(link));
+    dst[1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(count));
+}
+
+// Descriptor of the single item at permutation position a.
+__device__ __forceinline__ void put_item(const SahGroupArgs &g, const SahLds &L, uint32_t group, uint32_t gs, uint32_t pair_base,
+                                         uint32_t y, uint32_t a) {
+    const uint32_t it = L.idx[a];
+    float lo[3] = {L.box[0][it], L.box[1][it], L.box[2][it]}, hi[3] = {L.box[3][it], L.box[4][it], L.box[5][it]};
+    uint32_t link, count;
+    if (g.level0) { link = gs + a; count = ((uint32_t)L.kind[it] << 28) | 1u; }       // link = final position, patched to the kind's slot later
+    else { link = __float_as_uint(g.desc_in[2 * (size_t)(gs + it)].w); count = __float_as_uint(g.desc_in[2 * (size_t)(gs + it) + 1].w); }
+    put_desc(g, group, pair_base, y, lo, hi, link, count);
+}
+
+__device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ float lane_f(float v, uint32_t j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)j)); }
+
+// Sweep on one axis: this lane's candidate sends item j left when (c_j, j) <= (c_i, i).  Returns A_L n_L + A_R n_R.
+__device__ __forceinline__ float sweep_axis(uint32_t k, uint32_t lane, float ci, const float lo[3], const float hi[3]) {
+    float llo[3] = {kFInf, kFInf, kFInf}, lhi[3] = {-kFInf, -kFInf, -kFInf};
+    float rlo[3] = {kFInf, kFInf, kFInf}, rhi[3] = {-kFInf, -kFInf, -kFInf};
+    uint32_t nl = 0;
+    for (uint32_t j = 0; j < k; j++) {
+        const float cj = lane_f(ci, j);
+        const bool inl = cj < ci || (cj == ci && j <= lane);
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float bl = lane_f(lo[a], j), bh = lane_f(hi[a], j);
+            llo[a] = fminf(llo[a], inl ? bl : kFInf); lhi[a] = fmaxf(lhi[a], inl ? bh : -kFInf);
+            rlo[a] = fminf(rlo[a], inl ? kFInf : bl); rhi[a] = fmaxf(rhi[a], inl ? -kFInf : bh);
+        }
+        nl += inl ? 1u : 0u;
+    }
+    if (nl >= k) return kFInf;
+    const float cost = half_area3(llo, lhi) * (float)nl + half_area3(rlo, rhi) * (float)(k - nl);
+    return cost < kFInf ? cost : kFInf;      // also turns a NaN into "invalid"
+}
+
+// One wave builds the whole subtree of a node with at most kWaveNode items.
+__device__ void sah_wave_subtree(const SahGroupArgs &g, SahLds &L, uint32_t group, uint32_t gs, uint32_t pair_base, uint2 e,
+                                 uint32_t wave, uint32_t lane) {
+    uint2 *stk = L.wstack[wave];
+    uint32_t sp = 0;
+    for (;;) {
+        const uint32_t ex = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x), y = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+        const uint32_t a = ex & 0xFFFFu, b = ex >> 16, k = b - a, p = y & 0x7FFu;
+        if (k == 1) {
+            if (lane == 0) put_item(g, L, group, gs, pair_base, y, a);
+        } else {
+            const bool act = lane < k;
+            const uint32_t it = act ? L.idx[a + lane] : 0u;
+            float lo[3], hi[3], c[3], nlo[3], nhi[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+                lo[ax] = act ? L.box[ax][it] : kFInf; hi[ax] = act ? L.box[3 + ax][it] : -kFInf;
+                c[ax] = 0.5f * lo[ax] + 0.5f * hi[ax];
+                nlo[ax] = wave_min(lo[ax]); nhi[ax] = wave_max(hi[ax]);
+            }
+            const float area = half_area3(nlo, nhi);
+            // best split: minimum of A_L n_L + A_R n_R over every (axis, item) candidate
+            float best = kFInf; uint32_t best_ax = 0;
+            if (k == 2) { best = lane == 0 ? half_area3(lo, hi) + lane_f(half_area3(lo, hi), 1) : kFInf; }
+            else {
+                const float c0 = sweep_axis(k, lane, c[0], lo, hi);
+                const float c1 = sweep_axis(k, lane, c[1], lo, hi);
+                const float c2 = sweep_axis(k, lane, c[2], lo, hi);
+                best = c0; best_ax = 0;
+                if (c1 < best) { best = c1; best_ax = 1; }
+                if (c2 < best) { best = c2; best_ax = 2; }
+                if (!act) best = kFInf;
+            }
+            unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (best_ax * 64u + lane);
+            for (int o = 32; o > 0; o >>= 1) { unsigned long long other = __shfl_xor(key, o); key = other < key ? other : key; }
+            const uint32_t bl = (uint32_t)key & 63u, bax = ((uint32_t)key >> 6) & 3u;
+            const float split_cost = __uint_as_float((uint32_t)(key >> 32));
+            // multi-primitive leaf?  (level 0, one kind, at most max_leaf primitives, not more expensive than the split)
+            bool leaf = false;
+            const uint32_t kind = g.level0 ? (uint32_t)L.kind[it] : 0u;
+            if (g.level0 && k <= g.max_leaf) {
+                const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)kind, 0);
+                const bool same = __ballot(act && kind != k0) == 0ull;
+                leaf = same && g.c_isect * (float)k * area <= g.c_trav * area + g.c_isect * split_cost;
+            }
+            if (leaf) {
+                if (lane == 0) put_desc(g, group, pair_base, y, nlo, nhi, gs + a, (kind << 28) | k);
+            } else {
+                const float cme = bax == 0 ? c[0] : bax == 1 ? c[1] : c[2];
+                const float cb = lane_f(cme, bl);
+                bool inl = k == 2 ? lane == 0 : act && (cme < cb || (cme == cb && lane <= bl));
+                unsigned long long ml = __ballot(inl);
+                if (ml == 0ull || (uint32_t)__popcll(ml) >= k) { inl = lane < k / 2u; ml = __ballot(inl); }     // no finite candidate: halve the order
+                const unsigned long long mr = __ballot(act && !inl), lt = (1ull << lane) - 1ull;
+                const uint32_t nl = (uint32_t)__popcll(ml);
+                if (act) L.idx[a + (inl ? (uint32_t)__popcll(ml & lt) : nl + (uint32_t)__popcll(mr & lt))] = (uint16_t)it;
+                __threadfence_block();
+                if (lane == 0) put_desc(g, group, pair_base, y, nlo, nhi, pair_base + p, 0u);
+                const uint2 le = make_ent(a, a + nl, p + 1u, p, 0u), re = make_ent(a + nl, b, p + nl, p, 1u);
+                if (b - a - nl == 1u) { if (lane == 0) put_item(g, L, group, gs, pair_base, re.y, a + nl); }
+                else { stk[sp] = re; sp++; }
+                if (nl == 1u) { if (lane == 0) put_item(g, L, group, gs, pair_base, le.y, a); }
+                else { stk[sp] = le; sp++; }
+                __threadfence_block();
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        e = stk[sp];
+    }
+}
+
+__device__ __forceinline__ int bin_of(float c, float cmin, float scale) {
+    int b = (int)((c - cmin) * scale);
+    return b < 0 ? 0 : b > kBins - 1 ? kBins - 1 : b;
+}
+
+__global__ __launch_bounds__(256) void k_sah_group(SahGroupArgs g) {
+    __shared__ SahLds L;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t group = blockIdx.x;
+    const uint32_t gs = g.starts[group], ge = group + 1 < g.n_groups ? g.starts[group + 1] : g.n_items, m = ge - gs;
+    const uint32_t pair_base = g.pair_base + gs - group;
+    for (uint32_t i = tid; i < m; i += 256) {
+        float4 lo, hi;
+        if (g.level0) {
+            const uint32_t prim = g.vals[gs + i];
+            lo = g.plo[prim]; hi = g.phi[prim];
+            L.kind[i] = (uint8_t)(prim < g.n_spheres ? CRT_ID_KIND_SPHERE : prim < g.n_spheres + g.n_quads ? CRT_ID_KIND_QUAD : CRT_ID_KIND_TRI);
+        } else { lo = g.desc_in[2 * (size_t)(gs + i)]; hi = g.desc_in[2 * (size_t)(gs + i) + 1]; }
+        L.box[0][i] = lo.x; L.box[1][i] = lo.y; L.box[2][i] = lo.z; L.box[3][i] = hi.x; L.box[4][i] = hi.y; L.box[5][i] = hi.z;
+        L.idx[i] = (uint16_t)i;
+    }
+    if (tid == 0) {
+        const uint2 root = make_uint2(0u | (m << 16), kEntRoot);
+        L.top = 0; L.n_small = 0; L.cursor = 0;
+        if (m > kWaveNode) { L.ent[0] = root; L.top = 1; } else { L.ent[2 * kGroup - 1] = root; L.n_small = 1; }
+    }
+    // ---- nodes with more than kWaveNode items: the whole workgroup, binned SAH ----
+    for (;;) {
+        __syncthreads();
+        const uint32_t top = L.top;
+        if (top == 0) break;
+        const uint2 e = L.ent[top - 1];
+        const uint32_t a = e.x & 0xFFFFu, b = e.x >> 16, k = b - a, p = e.y & 0x7FFu;
+        if (tid < 12) L.red[tid] = (tid % 6) < 3 ? 0xFFFFFFFFu : 0u;
+        for (uint32_t t = tid; t < 3 * kBins * 7; t += 256) { const uint32_t f = t % 7; L.bins[t] = f == 0 ? 0u : f <= 3 ? 0xFFFFFFFFu : 0u; }
+        __syncthreads();
+        {   // bounds of the centroids and of the node
+            float cmn[3] = {kFInf, kFInf, kFInf}, cmx[3] = {-kFInf, -kFInf, -kFInf}, bmn[3] = {kFInf, kFInf, kFInf}, bmx[3] = {-kFInf, -kFInf, -kFInf};
+            for (uint32_t i = a + tid; i < b; i += 256) {
+                const uint32_t it = L.idx[i];
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++) {
+                    const float lo = L.box[ax][it], hi = L.box[3 + ax][it], c = 0.5f * lo + 0.5f * hi;
+                    cmn[ax] = fminf(cmn[ax], c); cmx[ax] = fmaxf(cmx[ax], c); bmn[ax] = fminf(bmn[ax], lo); bmx[ax] = fmaxf(bmx[ax], hi);
+                }
+            }
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+                cmn[ax] = wave_min(cmn[ax]); cmx[ax] = wave_max(cmx[ax]); bmn[ax] = wave_min(bmn[ax]); bmx[ax] = wave_max(bmx[ax]);
+                if (lane == 0) {
+                    atomicMin(&L.red[ax], enc_f(cmn[ax])); atomicMax(&L.red[3 + ax], enc_f(cmx[ax]));
+                    atomicMin(&L.red[6 + ax], enc_f(bmn[ax])); atomicMax(&L.red[9 + ax], enc_f(bmx[ax]));
+                }
+            }
+        }
+        __syncthreads();
+        float cmin[3], scale[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) {
+            cmin[ax] = dec_f(L.red[ax]);
+            const float ext = dec_f(L.red[3 + ax]) - cmin[ax];
+            scale[ax] = ext > 0.0f ? (float)kBins / ext : 0.0f;
+        }
+        for (uint32_t i = a + tid; i < b; i += 256) {
+            const uint32_t it = L.idx[i];
+            uint32_t elo[3], ehi[3]; float c[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+                const float lo = L.box[ax][it], hi = L.box[3 + ax][it];
+                c[ax] = 0.5f * lo + 0.5f * hi; elo[ax] = enc_f(lo); ehi[ax] = enc_f(hi);
+            }
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+                uint32_t *bin = &L.bins[(ax * kBins + bin_of(c[ax], cmin[ax], scale[ax])) * 7];
+                atomicAdd(&bin[0], 1u);
+                atomicMin(&bin[1], elo[0]); atomicMin(&bin[2], elo[1]); atomicMin(&bin[3], elo[2]);
+                atomicMax(&bin[4], ehi[0]); atomicMax(&bin[5], ehi[1]); atomicMax(&bin[6], ehi[2]);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {     // 3 axes x 15 planes, one candidate per lane
+            float cost = kFInf; uint32_t nl = 0;
+            const uint32_t ax = lane >> 4, plane = lane & 15u;
+            if (lane < 48 && plane < kBins - 1) {
+                float llo[3] = {kFInf, kFInf, kFInf}, lhi[3] = {-kFInf, -kFInf, -kFInf}, rlo[3] = {kFInf, kFInf, kFInf}, rhi[3] = {-kFInf, -kFInf, -kFInf};
+                uint32_t nr = 0;
+                for (uint32_t bi = 0; bi < (uint32_t)kBins; bi++) {
+                    const uint32_t *bin = &L.bins[(ax * kBins + bi) * 7];
+                    const uint32_t cnt = bin[0];
+                    if (cnt == 0) continue;
+                    if (bi <= plane) { nl += cnt; for (int d = 0; d < 3; d++) { llo[d] = fminf(llo[d], dec_f(bin[1 + d])); lhi[d] = fmaxf(lhi[d], dec_f(bin[4 + d])); } }
+                    else { nr += cnt; for (int d = 0; d < 3; d++) { rlo[d] = fminf(rlo[d], dec_f(bin[1 + d])); rhi[d] = fmaxf(rhi[d], dec_f(bin[4 + d])); } }
+                }
+                if (nl != 0 && nr != 0) {
+                    cost = half_area3(llo, lhi) * (float)nl + half_area3(rlo, rhi) * (float)nr;
+                    if (!(cost < kFInf)) cost = kFInf;
+                }
+            }
+            unsigned long long key = ((unsigned long long)__float_as_uint(cost) << 32) | lane;
+            for (int o = 32; o > 0; o >>= 1) { unsigned long long other = __shfl_xor(key, o); key = other < key ? other : key; }
+            const uint32_t bl = (uint32_t)key & 63u;
+            const bool valid = __uint_as_float((uint32_t)(key >> 32)) < kFInf;
+            if (lane == bl) { L.best_axis = valid ? ax : 3u; L.best_plane = plane; L.best_nl = valid ? nl : k / 2u; }
+        }
+        __syncthreads();
+        const uint32_t bax = L.best_axis, bplane = L.best_plane, nl = L.best_nl;
+        if (bax < 3u) {      // stable partition of idx[a, b) (no valid plane: all centroids coincide, split the order in half)
+            const float cm = bax == 0 ? cmin[0] : bax == 1 ? cmin[1] : cmin[2], sc = bax == 0 ? scale[0] : bax == 1 ? scale[1] : scale[2];
+            uint32_t left_before = 0;
+            for (uint32_t base = a; base < b; base += 256) {
+                const uint32_t i = base + tid;
+                const bool valid = i < b;
+                const uint32_t it = valid ? L.idx[i] : 0u;
+                const float c = 0.5f * L.box[bax][it] + 0.5f * L.box[3 + bax][it];
+                const bool left = valid && (uint32_t)bin_of(c, cm, sc) <= bplane;
+                const unsigned long long ml = __ballot(left);
+                if (lane == 0) L.wave_cnt[wave] = (uint32_t)__popcll(ml);
+                __syncthreads();
+                uint32_t before = left_before, chunk = 0;
+                for (uint32_t w = 0; w < 4; w++) { const uint32_t cw = L.wave_cnt[w]; if (w < wave) before += cw; chunk += cw; }
+                const uint32_t lrank = before + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull));
+                if (valid) L.tmp[left ? a + lrank : a + nl + ((i - a) - lrank)] = (uint16_t)it;
+                left_before += chunk;
+                __syncthreads();
+            }
+            for (uint32_t i = a + tid; i < b; i += 256) L.idx[i] = L.tmp[i];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float nlo[3] = {dec_f(L.red[6]), dec_f(L.red[7]), dec_f(L.red[8])}, nhi[3] = {dec_f(L.red[9]), dec_f(L.red[10]), dec_f(L.red[11])};
+            put_desc(g, group, pair_base, e.y, nlo, nhi, pair_base + p, 0u);
+            uint32_t t = top - 1, ns = L.n_small;
+            const uint2 kids[2] = {make_ent(a, a + nl, p + 1u, p, 0u), make_ent(a + nl, b, p + nl, p, 1u)};
+            for (int c = 0; c < 2; c++) {
+                const uint32_t kc = (kids[c].x >> 16) - (kids[c].x & 0xFFFFu);
+                if (kc > kWaveNode) L.ent[t++] = kids[c]; else { L.ent[2 * kGroup - 1 - ns] = kids[c]; ns++; }
+            }
+            L.top = t; L.n_small = ns;
+        }
+    }
+    // ---- small subtrees: one wave each ----
+    const uint32_t n_small = L.n_small;
+    for (;;) {
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(&L.cursor, 1u);
+        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+        if (i >= n_small) break;
+        sah_wave_subtree(g, L, group, gs, pair_base, L.ent[2 * kGroup - 1 - i], wave, lane);
+    }
+    __syncthreads();
+    if (g.level0) for (uint32_t i = tid; i < m; i += 256) g.perm[gs + i] = g.vals[gs + L.idx[i]];
+}
+
+// Leaf links were written as final sorted positions; turn them into slots of the kind's packed array.
+__global__ void k_sah_patch_links(uint32_t n_halves, float4 *pairs, const uint32_t *leaf_link) {
+    uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_halves) return;
+    const uint32_t count = __float_as_uint(pairs[2 * (size_t)h + 1].w);
+    if ((count & 0x0FFFFFFFu) == 0u) return;       // inner node, hole or the empty pad leaf
+    float4 lo = pairs[2 * (size_t)h];
+    lo.w = __uint_as_float(leaf_link[__float_as_uint(lo.w)]);
+    pairs[2 * (size_t)h] = lo;
+}
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return false; } } while (0)
+
+static bool ensure_buf(DeviceBuffer &b, size_t bytes, std::string &err) {
+    if (b.bytes >= bytes && b.ptr) return true;
+    if (b.ptr) { hipError_t e = hipFree(b.ptr); (void)e; b.ptr = nullptr; b.bytes = 0; }
+    size_t want = bytes < 256 ? 256 : bytes;
+    HIP_TRY(hipMalloc(&b.ptr, want));
+    b.bytes = want;
+    return true;
+}
+
+// Rebuilds the topology over the Morton-sorted primitives `vals` (n >= 2) and writes all n - 1 sibling pairs (leaf
+// links = positions in st.perm, see k_sah_patch_links) and the final primitive order st.perm.
+bool build_sah(hipStream_t stream, const BuildInput &in, BuildState &st, const uint32_t *vals, std::string &err) {
+    const uint32_t n = st.n_prims;
+    const size_t cap = (size_t)n + 64;          // groups over all tiers (checked below)
+    if (!ensure_buf(st.sah_flag, (size_t)n * 4, err) || !ensure_buf(st.sah_ipos[0], (size_t)n * 4, err) || !ensure_buf(st.sah_ipos[1], (size_t)n * 4, err)) return false;
+    if (!ensure_buf(st.sah_starts, cap * 4, err) || !ensure_buf(st.sah_desc, cap * 2 * sizeof(float4), err) || !ensure_buf(st.perm, (size_t)n * 4, err)) return false;
+    size_t scan_bytes = 0;
+    HIP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, (uint32_t *)st.sah_flag.ptr, (uint32_t *)st.sah_ipos[0].ptr, n, rocprim::plus<uint32_t>(), stream));
+    if (!ensure_buf(st.temp, scan_bytes, err)) return false;
+
+    struct Tier { uint32_t n_items, n_groups; size_t starts_off; };
+    std::vector<Tier> tiers;
+    uint32_t items = n, cur = 0;
+    const uint32_t *ipos = nullptr;
+    size_t used = 0;
+    uint32_t *starts = (uint32_t *)st.sah_starts.ptr;
+    while (items > kGroup) {
+        if (tiers.size() >= 24) { err = "SAH refinement: too many tiers"; return false; }
+        uint32_t *next = (uint32_t *)st.sah_ipos[cur].ptr;
+        HIP_TRY(hipMemsetAsync(st.sah_flag.ptr, 0, (size_t)n * 4, stream));
+        hipLaunchKernelGGL(k_sah_flags, dim3((2 * n - 1 + 255) / 256), dim3(256), 0, stream, n, kGroup, (const uint32_t *)st.range_lo.ptr,
+                           (const uint32_t *)st.range_hi.ptr, (const uint32_t *)st.parent.ptr, ipos, (uint32_t *)st.sah_flag.ptr);
+        size_t tb = st.temp.bytes;
+        HIP_TRY(rocprim::inclusive_scan(st.temp.ptr, tb, (uint32_t *)st.sah_flag.ptr, next, n, rocprim::plus<uint32_t>(), stream));
+        uint32_t groups = 0;
+        HIP_TRY(hipMemcpyAsync(&groups, next + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (groups == 0 || groups >= items) { err = "SAH refinement: clustering made no progress"; return false; }
+        if (used + groups + 1 > cap) { err = "SAH refinement: tier table overflow"; return false; }
+        hipLaunchKernelGGL(k_sah_starts, dim3((n + 255) / 256), dim3(256), 0, stream, n, (const uint32_t *)st.sah_flag.ptr, (const uint32_t *)next, ipos, starts + used);
+        tiers.push_back({items, groups, used});
+        used += groups;
+        items = groups; ipos = next; cur ^= 1u;
+    }
+    HIP_TRY(hipMemsetAsync(starts + used, 0, 4, stream));      // last tier: one group that starts at item 0
+    tiers.push_back({items, 1u, used});
+
+    // pair bases: the last tier owns pairs [0, n_items - 1); tier t's groups follow the pairs of tier t + 1
+    std::vector<uint32_t> base(tiers.size(), 0u);
+    for (size_t t = tiers.size() - 1; t-- > 0;) base[t] = base[t + 1] + tiers[t + 1].n_items - tiers[t + 1].n_groups;
+    HIP_TRY(hipMemsetAsync(st.pairs.ptr, 0, (size_t)st.n_pairs * 4 * sizeof(float4), stream));
+    float4 *desc = (float4 *)st.sah_desc.ptr;
+    for (size_t t = 0; t < tiers.size(); t++) {
+        SahGroupArgs g;
+        g.starts = starts + tiers[t].starts_off; g.n_groups = tiers[t].n_groups; g.n_items = tiers[t].n_items; g.pair_base = base[t];
+        g.level0 = t == 0 ? 1u : 0u;
+        g.vals = vals; g.plo = (const float4 *)st.plo.ptr; g.phi = (const float4 *)st.phi.ptr; g.n_spheres = in.n_spheres; g.n_quads = in.n_quads;
+        g.desc_in = t == 0 ? nullptr : desc + 2 * tiers[t - 1].starts_off;
+        g.desc_out = t + 1 == tiers.size() ? nullptr : desc + 2 * tiers[t].starts_off;
+        g.pairs = (float4 *)st.pairs.ptr; g.perm = (uint32_t *)st.perm.ptr;
+        g.max_leaf = st.max_leaf < 1u ? 1u : st.max_leaf > 8u ? 8u : st.max_leaf; g.c_isect = st.c_isect; g.c_trav = st.c_trav;
+        hipLaunchKernelGGL(k_sah_group, dim3(g.n_groups), dim3(256), 0, stream, g);
+    }
+    HIP_TRY(hipGetLastError());
+    st.sah_tiers = (uint32_t)tiers.size();
+    return true;
+}
+
+bool patch_sah_links(hipStream_t stream, BuildState &st, std::string &err) {
+    const uint32_t halves = 2 * st.n_pairs;
+    hipLaunchKernelGGL(k_sah_patch_links, dim3((halves + 255) / 256), dim3(256), 0, stream, halves, (float4 *)st.pairs.ptr, (const uint32_t *)st.leaf_link.ptr);
+    HIP_TRY(hipGetLastError());
+    return true;
+}
+
+}  // namespace crt

@@ -151,8 +151,8 @@ int crt_create(int device, crt_context **out) {
         delete ctx;
         return CRT_ERR_HIP;
     }
-    if (hipMalloc(&ctx->stats.ptr, 256) != hipSuccess || hipMemset(ctx->stats.ptr, 0, 256) != hipSuccess) { delete ctx; return CRT_ERR_HIP; }
-    ctx->stats.bytes = 256;
+    if (hipMalloc(&ctx->stats.ptr, sizeof(DeviceStats)) != hipSuccess || hipMemset(ctx->stats.ptr, 0, sizeof(DeviceStats)) != hipSuccess) { delete ctx; return CRT_ERR_HIP; }
+    ctx->stats.bytes = sizeof(DeviceStats);
     *out = ctx;
     return CRT_OK;
 }
@@ -394,6 +394,14 @@ int crt_stats_read(crt_context *ctx, crt_stats *out) {
     out->rays = ds.rays; out->paths = ds.paths; out->node_visits = ds.node_visits; out->prim_tests = ds.prim_tests;
     out->last_render_ms = ctx->last_render_ms; out->last_build_ms = ctx->last_build_ms;
     out->last_extend_ms = ctx->last_extend_ms; out->last_extend_launches = ctx->last_extend_launches;
+    return CRT_OK;
+}
+
+int crt_loop_counters_read(crt_context *ctx, uint64_t *out, uint32_t n_words) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!out || n_words != 16 * 6) return fail(ctx, CRT_ERR_INVALID, "crt_loop_counters_read: out must hold 16 x 6 words");
+    CTX_HIP(hipStreamSynchronize(ctx->stream));
+    CTX_HIP(hipMemcpy(out, (const char *)ctx->stats.ptr + offsetof(DeviceStats, loop), 16 * 6 * 8, hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 

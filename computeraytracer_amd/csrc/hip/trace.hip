@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
     uint32_t *cursors = q.cursors + bounce * kShards * kCtrStride;
     const float4 *ro = q.ray_o[bounce & 1], *rd = q.ray_d[bounce & 1];
     unsigned long long nodes = 0, prims = 0;
+    unsigned long long c_iter = 0, c_inner = 0, c_inner_lanes = 0, c_leaf = 0, c_leaf_lanes = 0, c_refill = 0;     // COUNT only, wave-uniform
     if (blockIdx.x == 0 && threadIdx.x < kShards) {
         unsigned long long n = wave_sum((unsigned long long)counts[threadIdx.x * kCtrStride]);
         if (threadIdx.x == 0) atomicAdd(&stats->rays, n - dead);
@@ -265,7 +266,9 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
     uint32_t *stack = s_stack + threadIdx.x;
     for (;;) {
         const unsigned long long idle = __ballot(!busy);
+        if (COUNT) c_iter++;
         if (!drained && (uint32_t)__popcll(idle) >= q.refill) {
+            if (COUNT) c_refill++;
             if (pool_next >= pool_end) {
                 // fetch the next chunk: own sub-queue first, then the others of this XCD's residue class, then the rest
                 while (k < ns) {
@@ -309,9 +312,11 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
         Counts cnt = {0, 0};
         bool more = true;
         if (n_leaf >= q.leaf_lanes || !any_inner) {
+            if (COUNT) { c_leaf++; c_leaf_lanes += n_leaf; }
             if (at_leaf) more = trav_leaf<COUNT>(sc, tr, stack, 256, spill, cnt);
-        } else if (busy && !at_leaf) {
-            more = trav_inner<COUNT>(sc, tr, stack, 256, spill, cnt);
+        } else {
+            if (COUNT) { c_inner++; c_inner_lanes += (uint32_t)__popcll(__ballot(busy && !at_leaf)); }
+            if (busy && !at_leaf) more = trav_inner<COUNT>(sc, tr, stack, 256, spill, cnt);
         }
         if (!more) {
             q.hit[slot] = make_uint2(f2u(tr.best_t), tr.best_id);
@@ -321,7 +326,12 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
     }
     if (COUNT) {
         nodes = wave_sum(nodes); prims = wave_sum(prims);
-        if (lane == 0) { atomicAdd(&stats->node_visits, nodes); atomicAdd(&stats->prim_tests, prims); }
+        if (lane == 0) {
+            atomicAdd(&stats->node_visits, nodes); atomicAdd(&stats->prim_tests, prims);
+            unsigned long long *c = stats->loop[bounce];
+            atomicAdd(&c[0], c_iter); atomicAdd(&c[1], c_inner); atomicAdd(&c[2], c_inner_lanes);
+            atomicAdd(&c[3], c_leaf); atomicAdd(&c[4], c_leaf_lanes); atomicAdd(&c[5], c_refill);
+        }
     }
 }
 

@@ -114,6 +114,10 @@ int crt_stats_reset(crt_context *ctx);
 /* Makes the next dispatches count node visits and primitive tests too
  * (slower; used to measure the V and T terms of the bytes-per-ray model). */
 int crt_set_instrumented(crt_context *ctx, int on);
+/* Divergence profile of the instrumented k_wf_extend launches since the last crt_stats_reset: per bounce (16 rows)
+ * {loop iterations, inner-phase iterations, lanes stepping in them, leaf-phase iterations, lanes testing in them,
+ * iterations that refilled lanes}, summed over waves.  Build-only diagnostic (no counterpart in the reference). */
+int crt_loop_counters_read(crt_context *ctx, uint64_t *out, uint32_t n_words);
 /* Brackets every k_wf_extend launch (the dominant kernel) with HIP events on the context's stream so that
  * crt_stats.last_extend_ms reports its device time separately (bench.py's roofline figure). */
 int crt_set_kernel_timing(crt_context *ctx, int on);

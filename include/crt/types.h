@@ -155,7 +155,11 @@ typedef struct crt_config {
 /* crt_bvh_build flags */
 enum {
     CRT_BVH_LBVH       = 0,        /* Morton LBVH only (fast rebuild path) */
-    CRT_BVH_SAH_REFINE = 1u << 0   /* + binned-SAH refinement */
+    CRT_BVH_SAH_REFINE = 1u << 0,  /* + SAH refinement: the LBVH clusters, the topology is rebuilt top-down with a 16-bin SAH
+                                      (nodes of more than 64 items) and an exact sweep SAH (smaller nodes); may close
+                                      small same-kind subtrees as multi-primitive leaves */
+    CRT_BVH_LEAF_COLLAPSE = 1u << 1 /* LBVH only: keep the Morton topology but close subtrees as multi-primitive leaves
+                                      where the SAH prefers it (bottom-up, during the refit) */
 };
 
 /* The build's own BVH node (32 B).  Nodes are stored as sibling pairs:

@@ -189,18 +189,63 @@ def test_stats_count_hit_world_calls(ctx):
     assert st.node_visits > st.rays and st.prim_tests > 0 and st.last_render_ms > 0
 
 
+def _check_tree(nodes, sid, qid, tid, scene):
+    """Structure of the pair BVH: every primitive in exactly one leaf, every child box inside its parent's, leaves of
+    one kind with contiguous slots.  Returns (leaf sizes, depth)."""
+    n_prims = len(scene.spheres) + len(scene.quads) + len(scene.tris)
+    seen = {abi.KIND_SPHERE: np.zeros(len(sid), np.int32), abi.KIND_QUAD: np.zeros(len(qid), np.int32), abi.KIND_TRI: np.zeros(len(tid), np.int32)}
+    lo, hi, link, count = nodes["lo"], nodes["hi"], nodes["link"], nodes["count"]
+    sizes, depth, visited = [], 0, 0
+    stack = [(0, None, None, 1)]
+    while stack:
+        pair, plo, phi, d = stack.pop()
+        depth = max(depth, d)
+        for h in (2 * pair, 2 * pair + 1):
+            c = int(count[h])
+            if c == (abi.KIND_TRI << 28):
+                continue                      # the empty pad leaf of a one-primitive scene
+            visited += 1
+            if plo is not None:
+                assert (lo[h] >= plo).all() and (hi[h] <= phi).all(), f"child {h} leaves its parent's box"
+            if c == 0:
+                stack.append((int(link[h]), lo[h], hi[h], d + 1))
+            else:
+                kind, k = c >> 28, c & 0x0FFFFFFF
+                seen[kind][int(link[h]):int(link[h]) + k] += 1
+                sizes.append(k)
+    assert sum(sizes) == n_prims
+    for kind, arr in seen.items():
+        assert (arr == 1).all(), f"kind {kind}: a primitive is in {arr.min()}..{arr.max()} leaves"
+    m = np.uint32(0x3FFFFFFF)     # slot -> input index is a permutation per kind
+    assert np.array_equal(np.sort(sid & m), np.arange(len(scene.spheres))) and np.array_equal(np.sort(qid & m), np.arange(len(scene.quads)))
+    assert np.array_equal(np.sort(tid & m), np.arange(len(scene.tris)))
+    return np.array(sizes), depth
+
+
+@pytest.mark.parametrize("bvh", [abi.BVH_SAH_REFINE, abi.BVH_LEAF_COLLAPSE], ids=["sah", "collapse"])
 @pytest.mark.parametrize("name,w,h,n_iter", CASES + [("cirno", 96, 60, 2)])
-def test_sah_collapsed_bvh_bit_exact(ctx, golden_dir, name, w, h, n_iter):
+def test_refined_bvh_bit_exact(ctx, golden_dir, name, w, h, n_iter, bvh):
     scene = abi.builtin_scene(name, w, h, golden_dir)
-    img, ids, ps = _gpu_render(ctx, scene, w, h, n_iter, bvh=abi.BVH_SAH_REFINE, tracer=abi.TRACER_WAVEFRONT)
+    img, ids, ps = _gpu_render(ctx, scene, w, h, n_iter, bvh=bvh, tracer=abi.TRACER_WAVEFRONT)
     ref_img, ref_ids, _ = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_FAST)
     assert np.array_equal(ids, ref_ids)
     assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32))
     nodes, sid, qid, tid = ctx.bvh()
-    leaves = nodes[nodes["count"] != 0]
-    sizes = leaves["count"] & 0x0FFFFFFF
+    sizes, _ = _check_tree(nodes, sid, qid, tid, scene)
     assert sizes.max() <= 4
-    # the oracle walking the collapsed device tree agrees with brute force
+    # the oracle walking the refined device tree agrees with brute force
     a, i, _ = orc.render(scene, ps[:1], w, h, flags=orc.TRAVERSE_BUILD, build_bvh=(nodes, sid, qid, tid))
     b, j, _ = orc.render(scene, ps[:1], w, h, flags=orc.TRAVERSE_FAST)
     assert np.array_equal(i, j) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["grid:34", "book1"])
+def test_sah_tiers_and_megakernel(ctx, name):
+    # grid:34 = 1,156,000 triangles: more than 1024 level-1 groups, so the SAH build runs three tiers
+    w, h = 64, 40
+    scene = abi.builtin_scene(name, w, h)
+    img, ids, ps = _gpu_render(ctx, scene, w, h, 1, bvh=abi.BVH_SAH_REFINE, tracer=abi.TRACER_MEGAKERNEL)
+    nodes, sid, qid, tid = ctx.bvh()
+    _check_tree(nodes, sid, qid, tid, scene)
+    lb_img, lb_ids, _ = _gpu_render(ctx, scene, w, h, 1, bvh=abi.BVH_LBVH, tracer=abi.TRACER_MEGAKERNEL)
+    assert np.array_equal(ids, lb_ids) and np.array_equal(img.view(np.uint32), lb_img.view(np.uint32))
