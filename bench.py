@@ -67,7 +67,8 @@ def main():
     ap.add_argument("--workload", default="lost_empire_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--tracer", default=os.environ.get("CRT_TRACER", "wavefront"), choices=["megakernel", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bvh", default=os.environ.get("CRT_BVH", "lbvh"), choices=["lbvh", "sah", "collapse"])
+    ap.add_argument("--bvh", default=os.environ.get("CRT_BVH", ""), choices=["", "lbvh", "sah", "collapse"],
+                    help="default: sah (static scenes), lbvh for the per-frame rebuild workload")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -84,6 +85,8 @@ def main():
     scene = abi.builtin_scene(scene_name, W, H, os.path.join(ROOT, "tests", "golden"))
     tracer = abi.TRACER_WAVEFRONT if args.tracer == "wavefront" else abi.TRACER_MEGAKERNEL
     rebuild = args.workload == "grid10m_1080p"
+    if not args.bvh:
+        args.bvh = "lbvh" if rebuild else "sah"
 
     ctx = abi.Context(local_rank)
     ctx.configure(W, H, tracer=tracer, band_rank=rank, band_world=world)
