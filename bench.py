@@ -67,8 +67,8 @@ def main():
     ap.add_argument("--workload", default="lost_empire_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--tracer", default=os.environ.get("CRT_TRACER", "wavefront"), choices=["megakernel", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bvh", default=os.environ.get("CRT_BVH", ""), choices=["", "lbvh", "sah", "collapse"],
-                    help="default: sah (static scenes), lbvh for the per-frame rebuild workload")
+    ap.add_argument("--bvh", default=os.environ.get("CRT_BVH", ""), choices=["", "lbvh", "sah", "collapse", "lbvh-wide", "sah-wide"],
+                    help="default: sah-wide (static scenes), lbvh-wide for the per-frame rebuild workload")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -86,12 +86,14 @@ def main():
     tracer = abi.TRACER_WAVEFRONT if args.tracer == "wavefront" else abi.TRACER_MEGAKERNEL
     rebuild = args.workload == "grid10m_1080p"
     if not args.bvh:
-        args.bvh = "lbvh" if rebuild else "sah"
+        args.bvh = "lbvh-wide" if rebuild else "sah-wide"
 
     ctx = abi.Context(local_rank)
     ctx.configure(W, H, tracer=tracer, band_rank=rank, band_world=world)
     ctx.upload(scene)
-    bvh_flags = {"lbvh": abi.BVH_LBVH, "sah": abi.BVH_SAH_REFINE, "collapse": abi.BVH_LEAF_COLLAPSE}[args.bvh]
+    bvh_flags = {"lbvh": abi.BVH_LBVH, "sah": abi.BVH_SAH_REFINE, "collapse": abi.BVH_LEAF_COLLAPSE,
+                 "lbvh-wide": abi.BVH_LBVH | abi.BVH_WIDE, "sah-wide": abi.BVH_SAH_REFINE | abi.BVH_WIDE}[args.bvh]
+    wide = args.bvh.endswith("-wide") and tracer == abi.TRACER_WAVEFRONT
     build_ms = ctx.build(bvh_flags)
     build_ms = ctx.build(bvh_flags)   # second build: allocations are warm, this is the device time of the build alone
     seeds = abi.frame_seeds(0, args.warmup + args.steps + 1)
@@ -159,11 +161,13 @@ def main():
     if rank == 0:
         mrays = rays / elapsed / 1e6
         # bytes/ray of the whole pipeline = 32 V + 48 T + 128 (queue entry written + read) + 32 / D (accumulation)
-        bytes_per_ray = 32.0 * V + 48.0 * T + (128.0 if tracer == abi.TRACER_WAVEFRONT else 0.0) + 32.0 / D
+        # node bytes per box tested: 32 (pair BVH: 32-byte nodes) or 8 (8-wide quantised nodes: 64 bytes loaded per 8 boxes)
+        node_b = 8.0 if wide else 32.0
+        bytes_per_ray = node_b * V + 48.0 * T + (128.0 if tracer == abi.TRACER_WAVEFRONT else 0.0) + 32.0 / D
         rank_rays = float(st.rays)
         if tracer == abi.TRACER_WAVEFRONT and st.last_extend_launches:
             # dominant kernel k_wf_extend: of that figure it moves 32 V + 48 T + 32 (ray read) + 8 (hit record written)
-            kernel_name, kernel_bytes_per_ray = "k_wf_extend", 32.0 * V + 48.0 * T + 40.0
+            kernel_name, kernel_bytes_per_ray = "k_wf_extend", node_b * V + 48.0 * T + 40.0
             n_launches = float(st.last_extend_launches) if not rebuild else float(st.last_extend_launches) * args.steps
             launch_ms = st.last_extend_ms / st.last_extend_launches
         else:

@@ -18,7 +18,7 @@ KIND_SPHERE, KIND_QUAD, KIND_TRI = 0, 1, 2
 RNG_REF, RNG_PCG = 0, 1
 TRACER_MEGAKERNEL, TRACER_WAVEFRONT = 0, 1
 FLAG_FULL_IMAGE = 1
-BVH_LBVH, BVH_SAH_REFINE, BVH_LEAF_COLLAPSE = 0, 1, 2
+BVH_LBVH, BVH_SAH_REFINE, BVH_LEAF_COLLAPSE, BVH_WIDE = 0, 1, 2, 4
 
 # numpy views of the POD layouts in include/crt/types.h
 sphere_dtype = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("pad0", "<f4", 3), ("materialIndex", "<u4")])
@@ -101,6 +101,7 @@ def _load():
         "crt_set_kernel_timing": (i32, [vp, i32]),
         "crt_loop_counters_read": (i32, [vp, vp, u32]),
         "crt_bvh_read": (i32, [vp, vp, P(u32), vp, vp, vp]),
+        "crt_bvh_wide_read": (i32, [vp, vp, P(u32), P(u32)]),
         "crt_camera_init": (None, [vp, P(f32), P(f32), f32, f32, f32, f32]),
         "crt_frame_seeds": (None, [u32, u32, vp]),
         "crt_quad_init": (None, [vp, P(f32), P(f32), P(f32), u32]),
@@ -360,3 +361,11 @@ class Context:
         t = np.zeros(len(sc.tris), dtype=np.uint32)
         self._check(lib.crt_bvh_read(self._h, _ptr(nodes), C.byref(n), _ptr(s), _ptr(q), _ptr(t)), "crt_bvh_read")
         return nodes, s | np.uint32(KIND_SPHERE << 30), q | np.uint32(KIND_QUAD << 30), t | np.uint32(KIND_TRI << 30)
+
+    def bvh_wide(self):
+        """(nodes as uint32[n, 32], levels): the 8-wide quantised nodes of a CRT_BVH_WIDE build (bvh_wide.hip)."""
+        n, lv = C.c_uint32(), C.c_uint32()
+        self._check(lib.crt_bvh_wide_read(self._h, None, C.byref(n), C.byref(lv)), "crt_bvh_wide_read")
+        nodes = np.zeros((n.value, 32), dtype=np.uint32)
+        self._check(lib.crt_bvh_wide_read(self._h, _ptr(nodes), C.byref(n), C.byref(lv)), "crt_bvh_wide_read")
+        return nodes, lv.value

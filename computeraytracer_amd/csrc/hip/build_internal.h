@@ -30,17 +30,25 @@ struct BuildState {
     uint32_t sah_tiers = 0;
     // results (what traversal reads)
     DeviceBuffer pairs, tri_pack, sphere_pack, quad_pack, sphere_ids, quad_ids, tri_ids;
+    // 8-wide quantised nodes (bvh_wide.hip, CRT_BVH_WIDE): n_wide nodes of kWideStrideF4 float4 each, BFS order
+    DeviceBuffer wide, wide_queue[2], wide_levels_dev;
+    uint32_t n_wide = 0, wide_levels = 0;
 };
+
+constexpr uint32_t kWideStrideF4 = 8;     // 128-byte node stride: the 64 bytes a step loads never straddle a line
+constexpr uint32_t kWideMaxLevels = 64;
 
 bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildState &st, std::string &err);
 bool build_sah(hipStream_t stream, const BuildInput &in, BuildState &st, const uint32_t *vals, std::string &err);
 bool patch_sah_links(hipStream_t stream, BuildState &st, std::string &err);
+bool build_wide(hipStream_t stream, BuildState &st, std::string &err);
 bool animate_tris(hipStream_t stream, uint32_t n, const crt_tri *rest, crt_tri *out, float frame, float amplitude, std::string &err);
 void free_build_state(BuildState &st);
 
 // ---- tracing (trace.hip) ----
 struct DeviceSceneHost {       // host-side mirror of DeviceScene (kept POD so context.hip need not include device headers)
     const void *nodes; uint32_t n_pairs;
+    const void *wide; uint32_t n_wide, wide_levels;     // 8-wide nodes (null: the wavefront tracer walks the pair BVH)
     const void *tri_pack, *sphere_pack, *quad_pack;
     const uint32_t *sphere_ids, *quad_ids;
     const crt_sphere *spheres; const crt_quad *quads; const crt_tri *tris;

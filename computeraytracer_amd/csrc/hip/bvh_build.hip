@@ -318,6 +318,8 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     const uint32_t n = in.n_spheres + in.n_quads + in.n_tris;
     st.n_prims = n;
     st.n_pairs = n == 0 ? 0 : (n == 1 ? 1 : n - 1);
+    st.n_wide = 0; st.wide_levels = 0;
+    const bool wide = (flags & CRT_BVH_WIDE) != 0;
     if (n == 0) return true;
     const uint32_t blocks = (n + 255) / 256;
     const size_t n4 = (size_t)n * sizeof(float4);
@@ -391,9 +393,12 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
         hipLaunchKernelGGL(k_single_pair, dim3(1), dim3(64), 0, stream, order, (const float4 *)st.plo.ptr, (const float4 *)st.phi.ptr,
                            (const uint32_t *)st.leaf_link.ptr, (const uint32_t *)st.leaf_count.ptr, (float4 *)st.pairs.ptr);
         HIP_TRY(hipGetLastError());
-        return true;
+        return wide ? build_wide(stream, st, err) : true;
     }
-    if (sah) return patch_sah_links(stream, st, err);
+    if (sah) {
+        if (!patch_sah_links(stream, st, err)) return false;
+        return wide ? build_wide(stream, st, err) : true;
+    }
     HIP_TRY(hipMemsetAsync(st.flag_a.ptr, 0, (size_t)n * 4, stream));
     hipLaunchKernelGGL(k_refit_emit, dim3(blocks), dim3(256), 0, stream, (int)n, vals, (const float4 *)st.plo.ptr,
                        (const float4 *)st.phi.ptr, (const uint32_t *)st.child_l.ptr, (const uint32_t *)st.child_r.ptr,
@@ -401,7 +406,7 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
                        (float4 *)st.nlo.ptr, (float4 *)st.nhi.ptr, (float4 *)st.ninfo.ptr, (uint32_t *)st.flag_a.ptr, (float4 *)st.pairs.ptr,
                        (flags & CRT_BVH_LEAF_COLLAPSE) ? (st.max_leaf < 1u ? 1u : st.max_leaf > 8u ? 8u : st.max_leaf) : 1u, st.c_isect, st.c_trav);
     HIP_TRY(hipGetLastError());
-    return true;
+    return wide ? build_wide(stream, st, err) : true;
 }
 
 void free_build_state(BuildState &st) {
@@ -409,7 +414,7 @@ void free_build_state(BuildState &st) {
                            &st.rank_b, &st.leaf_link, &st.leaf_count, &st.child_l, &st.child_r, &st.parent, &st.nlo, &st.nhi, &st.ninfo,
                            &st.scene_bounds, &st.temp, &st.range_lo, &st.range_hi, &st.sah_flag, &st.sah_ipos[0],
                            &st.sah_ipos[1], &st.sah_starts, &st.sah_desc, &st.perm, &st.pairs, &st.tri_pack, &st.sphere_pack, &st.quad_pack, &st.sphere_ids,
-                           &st.quad_ids, &st.tri_ids};
+                           &st.quad_ids, &st.tri_ids, &st.wide, &st.wide_queue[0], &st.wide_queue[1], &st.wide_levels_dev};
     for (DeviceBuffer *b : all) if (b->ptr) { hipError_t e = hipFree(b->ptr); (void)e; b->ptr = nullptr; b->bytes = 0; }
 }
 

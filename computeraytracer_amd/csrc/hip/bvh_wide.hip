@@ -1,0 +1,223 @@
+// bvh_wide.hip -- collapse of the pair BVH into 8-wide nodes with 8-bit quantised child boxes (CRT_BVH_WIDE).
+//
+// Why: the wavefront tracer's extend kernel is bound by the vector L1's address path, which retires about one
+// 16-byte lane access to a distinct line per clock and CU (tools/ubench_nodefetch.hip), i.e. by the NUMBER of
+// divergent 16-byte loads per ray, not by bytes.  A pair visit costs four such loads for two boxes; a wide visit
+// costs four for eight.  The tree also shrinks from 64 B per primitive to ~25 B, most of it resident in the
+// 4 MiB L2 of each XCD.
+//
+// Node (128-byte stride, the first 64 bytes are what a traversal step loads):
+//   float4 0   {ox|ex, oy|ey, oz|ez, child_base<<8 | imask}
+//              o* = node origin as an fp32 with the low 8 mantissa bits cleared (rounded DOWN), e* = biased exponent
+//              of the per-axis grid step (2^(e-127)) in those low 8 bits; child_base = index of the first inner child
+//              (inner children are consecutive, in slot order); imask bit s = slot s is an inner node
+//   float4 1   {qlo_x[0..3], qlo_x[4..7], qlo_y[0..3], qlo_y[4..7]}      one byte per slot
+//   float4 2   {qlo_z[0..3], qlo_z[4..7], qhi_x[0..3], qhi_x[4..7]}
+//   float4 3   {qhi_y[0..3], qhi_y[4..7], qhi_z[0..3], qhi_z[4..7]}
+//   float4 4,5 link[8]: leaf slot = kLeafTag | kind << 29 | (count - 1) << 26 | first slot in the kind's array
+//              (loaded lazily, only when a leaf slot is actually hit); inner slot = its node index (diagnostic);
+//              empty slot = kLeafTag | 3 << 29
+//   float4 6,7 unused
+// Child box of slot s on axis a = [o_a + qlo * 2^e_a, o_a + qhi * 2^e_a] as REAL numbers; the build checks in
+// double precision that this interval contains the child's box of the pair BVH.  Empty slots have qlo = 255,
+// qhi = 0.
+//
+// Slots are assigned so that slot ^ octant(ray) is a front-to-back visiting order (Ylitie, Karras, Laine 2017):
+// a child whose centroid lies towards +x/+y/+z of the node centre prefers a slot with bit 0/1/2 set.
+//
+// Collapse: top-down, one thread per wide node, level by level.  A thread starts from the two children of a pair
+// and keeps replacing the inner child of largest surface area by that child's two children until it holds eight
+// children or only leaves.  Wide nodes are numbered in BFS order: index = (nodes of earlier levels) + position in
+// the level's queue, so the inner children of one node are consecutive.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+
+#include "build_internal.h"
+#include "bvh_common.h"
+
+namespace crt {
+
+constexpr uint32_t kWideLeafTag = 0x80000000u;
+constexpr uint32_t kWideEmptyLink = kWideLeafTag | (3u << 29);
+
+struct WideChild { float lo[3], hi[3]; uint32_t link, count; };
+
+__device__ __forceinline__ bool pad_leaf(uint32_t count) { return count != 0u && (count & 0x0FFFFFFFu) == 0u; }
+
+__device__ __forceinline__ void read_half(const float4 *half, WideChild &c) {
+    float4 a = half[0], b = half[1];
+    c.lo[0] = a.x; c.lo[1] = a.y; c.lo[2] = a.z; c.link = __float_as_uint(a.w);
+    c.hi[0] = b.x; c.hi[1] = b.y; c.hi[2] = b.z; c.count = __float_as_uint(b.w);
+}
+
+// level_count[l] = wide nodes of level l (queue length); level l reads queue l & 1 and appends to the other one.
+__global__ __launch_bounds__(128) void k_wide_level(const float4 *pairs, uint32_t level, uint32_t *level_count,
+                                                    const uint2 *q_in, uint2 *q_out, float4 *wide, uint32_t stride_f4) {
+    const uint32_t n_in = level_count[level];
+    uint32_t next_base = 0;                         // nodes of levels 0..level = index of the first node of level + 1
+    for (uint32_t l = 0; l <= level; l++) next_base += level_count[l];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
+        const uint2 w = q_in[i];
+        const uint32_t src = w.x, dst = w.y;
+        WideChild c[8];
+        int n = 0;
+        {
+            WideChild a, b;
+            read_half(pairs + 4 * (size_t)src, a);
+            read_half(pairs + 4 * (size_t)src + 2, b);
+            if (!pad_leaf(a.count)) c[n++] = a;
+            if (!pad_leaf(b.count)) c[n++] = b;
+        }
+        while (n < 8) {
+            int best = -1; float best_area = -1.0f;
+            for (int k = 0; k < n; k++) {
+                if (c[k].count != 0u) continue;
+                float a = half_area3(c[k].lo, c[k].hi);
+                if (a > best_area) { best_area = a; best = k; }
+            }
+            if (best < 0) break;
+            WideChild a, b;
+            const uint32_t p = c[best].link;
+            read_half(pairs + 4 * (size_t)p, a);
+            read_half(pairs + 4 * (size_t)p + 2, b);
+            const bool pa = pad_leaf(a.count), pb = pad_leaf(b.count);
+            if (pa && pb) { c[best] = c[n - 1]; n--; continue; }
+            if (pa) { c[best] = b; continue; }
+            c[best] = a;
+            if (!pb) c[n++] = b;
+        }
+        // node box, origin (rounded down to 16 mantissa bits) and per-axis grid step
+        float lo[3], hi[3], origin[3]; uint32_t ebits[3]; double scale[3];
+        for (int a = 0; a < 3; a++) {
+            lo[a] = c[0].lo[a]; hi[a] = c[0].hi[a];
+            for (int k = 1; k < n; k++) { lo[a] = fminf(lo[a], c[k].lo[a]); hi[a] = fmaxf(hi[a], c[k].hi[a]); }
+            uint32_t b = __float_as_uint(lo[a]), t = b & 0xFFFFFF00u;
+            if ((b & 0x80000000u) && t != b) t += 0x100u;          // negative: truncation moved it up, step one unit down
+            origin[a] = __uint_as_float(t);
+            const double ext = (double)hi[a] - (double)origin[a];
+            int e = -100;
+            if (ext > 0.0) { int x; (void)frexp(ext / 255.0, &x); e = x; }      // 2^x >= ext / 255
+            e = e < -100 ? -100 : e;
+            ebits[a] = (uint32_t)(e + 127);
+            scale[a] = ldexp(1.0, e);
+        }
+        // slot assignment: greedy maximum of sum_a (slot bit a ? +1 : -1) * (child centroid - node centre)_a
+        int slot_of[8]; bool slot_used[8], child_done[8];
+        for (int k = 0; k < 8; k++) { slot_used[k] = false; child_done[k] = false; slot_of[k] = -1; }
+        float dv[8][3];
+        for (int k = 0; k < n; k++)
+            for (int a = 0; a < 3; a++) dv[k][a] = (0.5f * c[k].lo[a] + 0.5f * c[k].hi[a]) - (0.5f * lo[a] + 0.5f * hi[a]);
+        for (int it = 0; it < n; it++) {
+            float best = -3.402823466e38f; int bk = -1, bs = -1;
+            for (int k = 0; k < n; k++) {
+                if (child_done[k]) continue;
+                for (int s = 0; s < 8; s++) {
+                    if (slot_used[s]) continue;
+                    float v = ((s & 1) ? dv[k][0] : -dv[k][0]) + ((s & 2) ? dv[k][1] : -dv[k][1]) + ((s & 4) ? dv[k][2] : -dv[k][2]);
+                    if (v > best) { best = v; bk = k; bs = s; }
+                }
+            }
+            if (bk < 0) {            // only NaN costs left: first free pair
+                for (int k = 0; k < n && bk < 0; k++) if (!child_done[k]) bk = k;
+                for (int s = 0; s < 8 && bs < 0; s++) if (!slot_used[s]) bs = s;
+            }
+            slot_of[bk] = bs; child_done[bk] = true; slot_used[bs] = true;
+        }
+        int child_in[8];
+        for (int s = 0; s < 8; s++) child_in[s] = -1;
+        for (int k = 0; k < n; k++) child_in[slot_of[k]] = k;
+        uint32_t imask = 0, n_inner = 0;
+        for (int s = 0; s < 8; s++) if (child_in[s] >= 0 && c[child_in[s]].count == 0u) { imask |= 1u << s; n_inner++; }
+        uint32_t qpos = 0;
+        if (n_inner) qpos = atomicAdd(&level_count[level + 1], n_inner);
+        const uint32_t child_base = next_base + qpos;
+        // quantise
+        uint32_t q[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};     // qlo x,y,z, qhi x,y,z; two dwords of four slots
+        uint32_t link[8];
+        uint32_t r = 0;
+        for (int s = 0; s < 8; s++) {
+            const int k = child_in[s];
+            const uint32_t sh = 8u * (uint32_t)(s & 3), wd = (uint32_t)(s >> 2);
+            if (k < 0) {
+                for (int a = 0; a < 3; a++) q[a][wd] |= 255u << sh;
+                link[s] = kWideEmptyLink;
+                continue;
+            }
+            for (int a = 0; a < 3; a++) {
+                const double o = (double)origin[a], sc = scale[a];
+                double fl = floor(((double)c[k].lo[a] - o) / sc), fh = ceil(((double)c[k].hi[a] - o) / sc);
+                fl = fl < 0.0 ? 0.0 : fl > 255.0 ? 255.0 : fl;
+                fh = fh < 0.0 ? 0.0 : fh > 255.0 ? 255.0 : fh;
+                while (fl > 0.0 && o + fl * sc > (double)c[k].lo[a]) fl -= 1.0;
+                while (fh < 255.0 && o + fh * sc < (double)c[k].hi[a]) fh += 1.0;
+                q[a][wd] |= (uint32_t)fl << sh;
+                q[3 + a][wd] |= (uint32_t)fh << sh;
+            }
+            if (c[k].count == 0u) {
+                link[s] = child_base + r;
+                q_out[qpos + r] = make_uint2(c[k].link, child_base + r);
+                r++;
+            } else {
+                const uint32_t kind = c[k].count >> 28, cnt = c[k].count & 0x0FFFFFFFu;
+                link[s] = kWideLeafTag | (kind << 29) | ((cnt - 1u) << 26) | c[k].link;
+            }
+        }
+        float4 *o = wide + (size_t)stride_f4 * dst;
+        o[0] = make_float4(__uint_as_float(__float_as_uint(origin[0]) | ebits[0]), __uint_as_float(__float_as_uint(origin[1]) | ebits[1]),
+                           __uint_as_float(__float_as_uint(origin[2]) | ebits[2]), __uint_as_float((child_base << 8) | imask));
+        o[1] = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
+        o[2] = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
+        o[3] = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
+        o[4] = make_float4(__uint_as_float(link[0]), __uint_as_float(link[1]), __uint_as_float(link[2]), __uint_as_float(link[3]));
+        o[5] = make_float4(__uint_as_float(link[4]), __uint_as_float(link[5]), __uint_as_float(link[6]), __uint_as_float(link[7]));
+    }
+}
+
+__global__ void k_wide_init(uint32_t *level_count, uint32_t n_levels, uint2 *q0) {
+    for (uint32_t i = threadIdx.x; i <= n_levels; i += blockDim.x) level_count[i] = i == 0 ? 1u : 0u;
+    if (threadIdx.x == 0) q0[0] = make_uint2(0u, 0u);       // pair 0 -> wide node 0
+}
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return false; } } while (0)
+
+static bool ensure_w(DeviceBuffer &b, size_t bytes, std::string &err) {
+    if (b.bytes >= bytes && b.ptr) return true;
+    if (b.ptr) { hipError_t e = hipFree(b.ptr); (void)e; b.ptr = nullptr; b.bytes = 0; }
+    size_t want = bytes < 256 ? 256 : bytes;
+    HIP_TRY(hipMalloc(&b.ptr, want));
+    b.bytes = want;
+    return true;
+}
+
+bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
+    st.n_wide = 0; st.wide_levels = 0;
+    if (st.n_pairs == 0) return true;
+    if (st.n_pairs >= (1u << 24)) { err = "wide BVH supports fewer than 2^24 nodes"; return false; }
+    // every wide node consumes at least one pair, so n_pairs bounds the node count and every level's queue
+    if (!ensure_w(st.wide, (size_t)st.n_pairs * kWideStrideF4 * sizeof(float4), err)) return false;
+    if (!ensure_w(st.wide_queue[0], (size_t)st.n_pairs * 8, err) || !ensure_w(st.wide_queue[1], (size_t)st.n_pairs * 8, err)) return false;
+    if (!ensure_w(st.wide_levels_dev, (kWideMaxLevels + 2) * 4, err)) return false;
+    uint32_t *lc = (uint32_t *)st.wide_levels_dev.ptr;
+    hipLaunchKernelGGL(k_wide_init, dim3(1), dim3(128), 0, stream, lc, kWideMaxLevels + 1, (uint2 *)st.wide_queue[0].ptr);
+    const uint32_t grid = std::min<uint32_t>(2048u, (st.n_pairs + 127u) / 128u);
+    uint32_t host_lc[kWideMaxLevels + 2];
+    uint32_t level = 0;
+    for (;;) {
+        const uint32_t chunk_end = std::min<uint32_t>(level + 8u, kWideMaxLevels);
+        for (; level < chunk_end; level++)
+            hipLaunchKernelGGL(k_wide_level, dim3(grid), dim3(128), 0, stream, (const float4 *)st.pairs.ptr, level, lc,
+                               (const uint2 *)st.wide_queue[level & 1].ptr, (uint2 *)st.wide_queue[(level & 1) ^ 1].ptr,
+                               (float4 *)st.wide.ptr, kWideStrideF4);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host_lc, lc, (kWideMaxLevels + 2) * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (host_lc[level] == 0) break;
+        if (level >= kWideMaxLevels) { err = "wide BVH deeper than 64 levels"; return false; }
+    }
+    for (uint32_t l = 0; l <= kWideMaxLevels && host_lc[l]; l++) { st.n_wide += host_lc[l]; st.wide_levels = l + 1; }
+    return true;
+}
+
+}  // namespace crt

@@ -73,6 +73,7 @@ uint32_t local_bands(uint32_t grid_h, uint32_t rank, uint32_t world) {
 DeviceSceneHost scene_view(const crt_context *ctx) {
     DeviceSceneHost s{};
     s.nodes = ctx->build.pairs.ptr; s.n_pairs = ctx->build.n_pairs;
+    s.wide = ctx->build.n_wide ? ctx->build.wide.ptr : nullptr; s.n_wide = ctx->build.n_wide; s.wide_levels = ctx->build.wide_levels;
     s.tri_pack = ctx->build.tri_pack.ptr; s.sphere_pack = ctx->build.sphere_pack.ptr; s.quad_pack = ctx->build.quad_pack.ptr;
     s.sphere_ids = (const uint32_t *)ctx->build.sphere_ids.ptr; s.quad_ids = (const uint32_t *)ctx->build.quad_ids.ptr;
     s.spheres = (const crt_sphere *)ctx->spheres.ptr; s.quads = (const crt_quad *)ctx->quads.ptr; s.tris = (const crt_tri *)ctx->tris.ptr;
@@ -433,6 +434,17 @@ int crt_bvh_read(crt_context *ctx, crt_bvh_node *nodes, uint32_t *n_nodes, uint3
     if (sphere_ids && ctx->n_spheres) CTX_HIP(hipMemcpy(sphere_ids, ctx->build.sphere_ids.ptr, (size_t)ctx->n_spheres * 4, hipMemcpyDeviceToHost));
     if (quad_ids && ctx->n_quads) CTX_HIP(hipMemcpy(quad_ids, ctx->build.quad_ids.ptr, (size_t)ctx->n_quads * 4, hipMemcpyDeviceToHost));
     if (tri_ids && ctx->n_tris) CTX_HIP(hipMemcpy(tri_ids, ctx->build.tri_ids.ptr, (size_t)ctx->n_tris * 4, hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt_bvh_wide_read(crt_context *ctx, void *nodes, uint32_t *n_nodes, uint32_t *n_levels) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!ctx->have_bvh) return fail(ctx, CRT_ERR_INVALID, "crt_bvh_wide_read: no BVH built");
+    if (!n_nodes) return fail(ctx, CRT_ERR_INVALID, "crt_bvh_wide_read: null n_nodes");
+    *n_nodes = ctx->build.n_wide;
+    if (n_levels) *n_levels = ctx->build.wide_levels;
+    CTX_HIP(hipStreamSynchronize(ctx->stream));
+    if (nodes && ctx->build.n_wide) CTX_HIP(hipMemcpy(nodes, ctx->build.wide.ptr, (size_t)ctx->build.n_wide * kWideStrideF4 * 16, hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 

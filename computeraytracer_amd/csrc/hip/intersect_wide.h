@@ -1,0 +1,141 @@
+// intersect_wide.h -- closest-hit search over the 8-wide quantised BVH (node format: bvh_wide.hip).
+//
+// One step = four 16-byte loads (header + 48 quantised plane bytes), eight slab tests, one 8-bit hit mask.
+// The hit children of a node wait as ONE stack entry {child_base | imask, node | pending mask}; the pending mask
+// is stored in visiting order (bit position = slot ^ ray octant), so "next child" is the lowest set bit.  The top
+// entry lives in registers.  Inner children are addressed as child_base + popcount(imask below slot); the link of a
+// leaf slot is loaded only when that slot is actually taken.
+//
+// Conservativeness.  The planes of a child box are the real numbers P = origin + q * 2^e.  A step evaluates
+// t = q * A + B with A = (1/d) * 2^e (exact) and B = fma(origin, 1/d, -(o * 1/d)); the rounding of 1/d, of o * 1/d,
+// of B and of the final fma moves t by at most 2^-23 |t| + 2^-24 (|o/d| + |B|).  Near planes therefore use
+// B - err, far planes (B + err) * (1 + 2^-20) with err = 2^-22 (|o/d| + |B|), and the far bound is the best hit
+// so far times (1 + 2^-18): a child whose true box the ray enters before the best hit is never culled.
+#pragma once
+#include "intersect.h"
+
+namespace crt {
+
+#ifndef CRT_WIDE_LDS_STACK
+#define CRT_WIDE_LDS_STACK 12
+#endif
+constexpr int kWideLds = CRT_WIDE_LDS_STACK;          // 8-byte entries per lane in LDS; deeper levels spill to scratch
+constexpr int kWideSpill = 64 - CRT_WIDE_LDS_STACK;   // the build refuses trees deeper than 64 levels
+constexpr uint32_t kWideNodeF4 = 8;                   // = kWideStrideF4 (build_internal.h)
+constexpr uint32_t kEmptyLeaf = kLeafTag | (3u << 29);
+
+struct WideTrav {
+    V3 o, d, idir, noid;
+    float best_t, tfar;
+    uint32_t best_id;
+    uint32_t cur;              // inner: node index; leaf: tagged entry (kLeafTag | kind | count | first)
+    uint32_t g_hdr, g_pend;    // top group: child_base << 8 | imask ; node << 8 | pending mask in visiting order
+    uint32_t oct;              // bit a set: direction component a is negative
+    int sp;
+};
+
+CRT_DEV void wide_begin(WideTrav &tr, V3 o, V3 d) {
+    tr.o = o; tr.d = d;
+    tr.idir.x = __builtin_fabsf(d.x) > 1e-30f ? 1.0f / d.x : __builtin_copysignf(1e30f, d.x);
+    tr.idir.y = __builtin_fabsf(d.y) > 1e-30f ? 1.0f / d.y : __builtin_copysignf(1e30f, d.y);
+    tr.idir.z = __builtin_fabsf(d.z) > 1e-30f ? 1.0f / d.z : __builtin_copysignf(1e30f, d.z);
+    tr.noid = mk3(-(o.x * tr.idir.x), -(o.y * tr.idir.y), -(o.z * tr.idir.z));
+    tr.oct = (f2u(tr.idir.x) >> 31) | ((f2u(tr.idir.y) >> 31) << 1) | ((f2u(tr.idir.z) >> 31) << 2);
+    tr.best_t = kInf; tr.tfar = kInf; tr.best_id = kIdMiss;
+    tr.cur = 0; tr.g_hdr = 0; tr.g_pend = 0; tr.sp = 0;
+}
+
+// Next child in visiting order; false when nothing is left (best_t / best_id are final).
+// SPILL = false: the tree has at most kWideLds + 1 levels, so the LDS stack cannot overflow and no scratch is touched.
+template <bool SPILL>
+CRT_DEV bool wide_advance(const float4 *nodes, WideTrav &tr, const uint2 *stack, uint32_t stack_stride, const uint2 *spill) {
+    if ((tr.g_pend & 0xFFu) == 0u) {
+        if (tr.sp == 0) return false;
+        tr.sp--;
+        uint2 e;
+        if (!SPILL || tr.sp < kWideLds) e = stack[tr.sp * stack_stride];
+        else e = spill[tr.sp - kWideLds];
+        tr.g_hdr = e.x; tr.g_pend = e.y;
+    }
+    const uint32_t pos = (uint32_t)__builtin_ctz(tr.g_pend);        // the mask is non-zero, so this is one of its 8 bits
+    tr.g_pend &= tr.g_pend - 1u;
+    const uint32_t slot = pos ^ tr.oct, imask = tr.g_hdr & 0xFFu;
+    if ((imask >> slot) & 1u) tr.cur = (tr.g_hdr >> 8) + (uint32_t)__builtin_popcount(imask & ((1u << slot) - 1u));
+    else tr.cur = ((const uint32_t *)nodes)[(size_t)(tr.g_pend >> 8) * (kWideNodeF4 * 4u) + 16u + slot];
+    return true;
+}
+
+CRT_DEV float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }     // v_cvt_f32_ubyteK
+
+// Inner step: tr.cur is a node index.
+template <bool COUNT, bool SPILL>
+CRT_DEV bool wide_inner(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_t stack_stride, uint2 *spill, Counts &cnt) {
+    const uint32_t node = tr.cur;
+    const float4 *p = nodes + (size_t)kWideNodeF4 * node;
+    const float4 h = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+    if (COUNT) cnt.nodes += 8;
+    const uint32_t hx = f2u(h.x), hy = f2u(h.y), hz = f2u(h.z);
+    constexpr float kErr = 2.384185791015625e-07f;     // 2^-22
+    constexpr float kFar = 1.00000095367431640625f;    // 1 + 2^-20
+    // per-axis plane coefficients: t_near = q * an + bn, t_far = q * af + bf
+    const float ax = tr.idir.x * u2f((hx & 0xFFu) << 23), ay = tr.idir.y * u2f((hy & 0xFFu) << 23), az = tr.idir.z * u2f((hz & 0xFFu) << 23);
+    const float bx = __builtin_fmaf(u2f(hx & 0xFFFFFF00u), tr.idir.x, tr.noid.x);
+    const float by = __builtin_fmaf(u2f(hy & 0xFFFFFF00u), tr.idir.y, tr.noid.y);
+    const float bz = __builtin_fmaf(u2f(hz & 0xFFFFFF00u), tr.idir.z, tr.noid.z);
+    const float ex = (__builtin_fabsf(tr.noid.x) + __builtin_fabsf(bx)) * kErr;
+    const float ey = (__builtin_fabsf(tr.noid.y) + __builtin_fabsf(by)) * kErr;
+    const float ez = (__builtin_fabsf(tr.noid.z) + __builtin_fabsf(bz)) * kErr;
+    const float bnx = bx - ex, bny = by - ey, bnz = bz - ez;
+    const float afx = ax * kFar, afy = ay * kFar, afz = az * kFar;
+    const float bfx = (bx + ex) * kFar, bfy = (by + ey) * kFar, bfz = (bz + ez) * kFar;
+    // near planes are the low ones for a non-negative direction component, the high ones otherwise
+    const bool nx = (tr.oct & 1u) != 0u, ny = (tr.oct & 2u) != 0u, nz = (tr.oct & 4u) != 0u;
+    const uint32_t lox[2] = {f2u(r1.x), f2u(r1.y)}, loy[2] = {f2u(r1.z), f2u(r1.w)}, loz[2] = {f2u(r2.x), f2u(r2.y)};
+    const uint32_t hix[2] = {f2u(r2.z), f2u(r2.w)}, hiy[2] = {f2u(r3.x), f2u(r3.y)}, hiz[2] = {f2u(r3.z), f2u(r3.w)};
+    uint32_t m = 0;
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        const uint32_t qnx = nx ? hix[w] : lox[w], qfx = nx ? lox[w] : hix[w];
+        const uint32_t qny = ny ? hiy[w] : loy[w], qfy = ny ? loy[w] : hiy[w];
+        const uint32_t qnz = nz ? hiz[w] : loz[w], qfz = nz ? loz[w] : hiz[w];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float tnx = __builtin_fmaf(ubyte_f(qnx, k), ax, bnx), tfx = __builtin_fmaf(ubyte_f(qfx, k), afx, bfx);
+            const float tny = __builtin_fmaf(ubyte_f(qny, k), ay, bny), tfy = __builtin_fmaf(ubyte_f(qfy, k), afy, bfy);
+            const float tnz = __builtin_fmaf(ubyte_f(qnz, k), az, bnz), tfz = __builtin_fmaf(ubyte_f(qfz, k), afz, bfz);
+            const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
+            const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tr.tfar));
+            if (tn <= tf) m |= 1u << (4 * w + k);
+        }
+    }
+    if (m != 0u) {
+        // visiting order: bit position = slot ^ octant
+        uint32_t pm = m;
+        if (tr.oct & 1u) pm = ((pm & 0x55u) << 1) | ((pm >> 1) & 0x55u);
+        if (tr.oct & 2u) pm = ((pm & 0x33u) << 2) | ((pm >> 2) & 0x33u);
+        if (tr.oct & 4u) pm = ((pm & 0x0Fu) << 4) | (pm >> 4);
+        if ((tr.g_pend & 0xFFu) != 0u) {
+            const uint2 e = make_uint2(tr.g_hdr, tr.g_pend);
+            if (!SPILL || tr.sp < kWideLds) stack[tr.sp * stack_stride] = e;
+            else if (tr.sp < kWideLds + kWideSpill) spill[tr.sp - kWideLds] = e;
+            tr.sp++;
+        }
+        tr.g_hdr = f2u(h.w);
+        tr.g_pend = (node << 8) | pm;
+    }
+    return wide_advance<SPILL>(nodes, tr, stack, stack_stride, spill);
+}
+
+// Leaf step: tr.cur is a tagged leaf entry.
+template <bool COUNT, bool SPILL>
+CRT_DEV bool wide_leaf(const DeviceScene &sc, WideTrav &tr, const uint2 *stack, uint32_t stack_stride, const uint2 *spill, Counts &cnt) {
+    const uint32_t e = tr.cur;
+    const uint32_t kind = (e >> 29) & 3u, n = ((e >> 26) & 7u) + 1u, first = e & (kMaxLeafLink - 1u);
+    if (kind != 3u) {                                   // 3 = empty slot (a box test can only reach it through rounding)
+        test_leaf<COUNT>(sc, tr.o, tr.d, first, (kind << 28) | n, tr.best_t, tr.best_id, cnt);
+        tr.tfar = tr.best_t * 1.000004f;                // relative pad (2^-18) on the far bound
+    }
+    return wide_advance<SPILL>(sc.wide, tr, stack, stack_stride, spill);
+}
+
+}  // namespace crt

@@ -13,6 +13,7 @@
 
 #include "build_internal.h"
 #include "shade.h"
+#include "intersect_wide.h"
 
 namespace crt {
 
@@ -27,6 +28,7 @@ struct Frame {
 static DeviceScene to_device_scene(const DeviceSceneHost &h) {
     DeviceScene d;
     d.nodes = (const float4 *)h.nodes; d.n_pairs = h.n_pairs;
+    d.wide = (const float4 *)h.wide; d.n_wide = h.n_wide;
     d.tri_pack = (const float4 *)h.tri_pack; d.sphere_pack = (const float4 *)h.sphere_pack; d.quad_pack = (const float4 *)h.quad_pack;
     d.sphere_ids = h.sphere_ids; d.quad_ids = h.quad_ids;
     d.spheres = h.spheres; d.quads = h.quads; d.tris = h.tris; d.materials = h.materials;
@@ -227,12 +229,37 @@ __device__ __forceinline__ uint32_t home_shard(uint32_t block, uint32_t wave, ui
 // only be refilled from cursors that grow monotonically up to fixed sizes.
 constexpr uint32_t kRefillLanes = 16;
 
+// Per-lane traversal state behind one interface, so that k_wf_extend is written once for both node formats.  The
+// overflow ("spill") part of the stack is a separate local array handed in by pointer: inside the struct its dynamic
+// indexing would keep the whole state in scratch memory.  SPILL = false (wide format only) when the tree is shallow
+// enough for the LDS stack.
+template <bool WIDE, bool SPILL> struct LaneTrav;
+template <bool SPILL> struct LaneTrav<false, SPILL> {          // sibling-pair BVH (intersect.h)
+    using Entry = uint32_t;
+    static constexpr int kSpill = kSpillStack;
+    Traversal tr;
+    CRT_DEV void begin(V3 o, V3 d) { trav_begin(tr, o, d); }
+    CRT_DEV bool at_leaf() const { return (tr.cur & kLeafTag) != 0; }
+    template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, Entry *stack, Entry *spill, Counts &c) { return trav_inner<COUNT>(sc, tr, stack, 256, spill, c); }
+    template <bool COUNT> CRT_DEV bool leaf(const DeviceScene &sc, Entry *stack, Entry *spill, Counts &c) { return trav_leaf<COUNT>(sc, tr, stack, 256, spill, c); }
+};
+template <bool SPILL> struct LaneTrav<true, SPILL> {           // 8-wide quantised BVH (intersect_wide.h)
+    using Entry = uint2;
+    static constexpr int kSpill = SPILL ? kWideSpill : 1;
+    WideTrav tr;
+    CRT_DEV void begin(V3 o, V3 d) { wide_begin(tr, o, d); }
+    CRT_DEV bool at_leaf() const { return (tr.cur & kLeafTag) != 0; }
+    template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, Entry *stack, Entry *spill, Counts &c) { return wide_inner<COUNT, SPILL>(sc.wide, tr, stack, 256, spill, c); }
+    template <bool COUNT> CRT_DEV bool leaf(const DeviceScene &sc, Entry *stack, Entry *spill, Counts &c) { return wide_leaf<COUNT, SPILL>(sc, tr, stack, 256, spill, c); }
+};
+static_assert(kLdsStack * 4 == kWideLds * 8, "both stack layouts use the same LDS block");
+
 #ifndef CRT_EXTEND_WAVES
 #define CRT_EXTEND_WAVES 6
 #endif
-template <bool COUNT>
+template <bool COUNT, bool WIDE, bool SPILL>
 __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene sc, WfQueues q, uint32_t bounce, unsigned long long dead, DeviceStats *stats) {
-    __shared__ uint32_t s_stack[kLdsStack * 256];
+    __shared__ uint2 s_stack[kWideLds * 256];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t *counts = q.counts + bounce * kShards * kCtrStride;
     uint32_t *cursors = q.cursors + bounce * kShards * kCtrStride;
@@ -261,9 +288,10 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
     // per-lane state
     bool busy = false;
     uint32_t slot = 0;
-    Traversal tr;
-    uint32_t spill[kSpillStack];
-    uint32_t *stack = s_stack + threadIdx.x;
+    using LT = LaneTrav<WIDE, SPILL>;
+    LT lt;
+    typename LT::Entry spill[LT::kSpill];
+    typename LT::Entry *stack = (typename LT::Entry *)s_stack + threadIdx.x;
     for (;;) {
         const unsigned long long idle = __ballot(!busy);
         if (COUNT) c_iter++;
@@ -295,7 +323,7 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
                     slot = pool_base + i;
                     float4 o4 = ro[slot], d4 = rd[slot];
                     if (f2u(d4.w) == kDeadPixel) q.hit[slot] = make_uint2(f2u(kInf), kIdMiss);
-                    else { trav_begin(tr, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z)); busy = true; }
+                    else { lt.begin(mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z)); busy = true; }
                 }
                 pool_next = min(pool_end, pool_next + (uint32_t)__popcll(idle));
             }
@@ -306,20 +334,20 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
         }
         // while-while: lanes whose cursor is a leaf wait until enough of them have one (or nobody can descend),
         // then the wave runs one leaf-test phase; otherwise the others do one inner step
-        const bool at_leaf = busy && (tr.cur & kLeafTag) != 0;
+        const bool at_leaf = busy && lt.at_leaf();
         const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
         const bool any_inner = __ballot(busy && !at_leaf) != 0;
         Counts cnt = {0, 0};
         bool more = true;
         if (n_leaf >= q.leaf_lanes || !any_inner) {
             if (COUNT) { c_leaf++; c_leaf_lanes += n_leaf; }
-            if (at_leaf) more = trav_leaf<COUNT>(sc, tr, stack, 256, spill, cnt);
+            if (at_leaf) more = lt.template leaf<COUNT>(sc, stack, spill, cnt);
         } else {
             if (COUNT) { c_inner++; c_inner_lanes += (uint32_t)__popcll(__ballot(busy && !at_leaf)); }
-            if (busy && !at_leaf) more = trav_inner<COUNT>(sc, tr, stack, 256, spill, cnt);
+            if (busy && !at_leaf) more = lt.template inner<COUNT>(sc, stack, spill, cnt);
         }
         if (!more) {
-            q.hit[slot] = make_uint2(f2u(tr.best_t), tr.best_id);
+            q.hit[slot] = make_uint2(f2u(lt.tr.best_t), lt.tr.best_id);
             busy = false;
         }
         if (COUNT) { nodes += cnt.nodes; prims += cnt.prims; }
@@ -461,8 +489,16 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
             if (wf.ev_used + 2 > wf.ev.size()) { hipEvent_t a, c; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&c)); wf.ev.push_back(a); wf.ev.push_back(c); }
             HIP_TRY(hipEventRecord(wf.ev[wf.ev_used], stream));
         }
-        if (fs.instrumented) hipLaunchKernelGGL((k_wf_extend<true>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
-        else hipLaunchKernelGGL((k_wf_extend<false>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
+        if (sc.wide && sch.wide_levels <= (uint32_t)kWideLds + 1u) {      // at most levels - 1 groups wait on the stack
+            if (fs.instrumented) hipLaunchKernelGGL((k_wf_extend<true, true, false>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
+            else hipLaunchKernelGGL((k_wf_extend<false, true, false>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
+        } else if (sc.wide) {
+            if (fs.instrumented) hipLaunchKernelGGL((k_wf_extend<true, true, true>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
+            else hipLaunchKernelGGL((k_wf_extend<false, true, true>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
+        } else {
+            if (fs.instrumented) hipLaunchKernelGGL((k_wf_extend<true, false, true>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
+            else hipLaunchKernelGGL((k_wf_extend<false, false, true>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
+        }
         if (wf.time_kernels) { HIP_TRY(hipEventRecord(wf.ev[wf.ev_used + 1], stream)); wf.ev_used += 2; }
         if (pcg) hipLaunchKernelGGL((k_wf_shade<1>), pgrid, block, 0, stream, sc, f, q, b, acc, hit_ids);
         else hipLaunchKernelGGL((k_wf_shade<0>), pgrid, block, 0, stream, sc, f, q, b, acc, hit_ids);

@@ -128,6 +128,12 @@ int crt_set_kernel_timing(crt_context *ctx, int on);
 int crt_bvh_read(crt_context *ctx, crt_bvh_node *nodes, uint32_t *n_nodes,
                  uint32_t *sphere_ids, uint32_t *quad_ids, uint32_t *tri_ids);
 
+/* Read back the 8-wide nodes built with CRT_BVH_WIDE (128 bytes each, layout in
+ * computeraytracer_amd/csrc/hip/bvh_wide.hip; node 0 is the root, BFS order) for cross-checks.
+ * Two-call protocol: pass nodes = NULL to get the count (0 when the BVH was built without the flag).
+ * Build-only diagnostic, no counterpart in the reference. */
+int crt_bvh_wide_read(crt_context *ctx, void *nodes, uint32_t *n_nodes, uint32_t *n_levels);
+
 /* ---- host-side helpers (no GPU needed) --------------------------------- */
 
 /* Camera::Camera + Camera::calculateProperties (raytracing/src/camera.cpp:3-12,40-62):

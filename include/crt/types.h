@@ -158,8 +158,11 @@ enum {
     CRT_BVH_SAH_REFINE = 1u << 0,  /* + SAH refinement: the LBVH clusters, the topology is rebuilt top-down with a 16-bin SAH
                                       (nodes of more than 64 items) and an exact sweep SAH (smaller nodes); may close
                                       small same-kind subtrees as multi-primitive leaves */
-    CRT_BVH_LEAF_COLLAPSE = 1u << 1 /* LBVH only: keep the Morton topology but close subtrees as multi-primitive leaves
+    CRT_BVH_LEAF_COLLAPSE = 1u << 1, /* LBVH only: keep the Morton topology but close subtrees as multi-primitive leaves
                                       where the SAH prefers it (bottom-up, during the refit) */
+    CRT_BVH_WIDE = 1u << 2          /* + collapse the pair BVH into 8-wide nodes with 8-bit quantised child boxes
+                                      (128-byte stride, 64 bytes loaded per visit); the wavefront tracer walks these,
+                                      the megakernel and crt_bvh_read keep using the pair BVH */
 };
 
 /* The build's own BVH node (32 B).  Nodes are stored as sibling pairs:

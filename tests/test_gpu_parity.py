@@ -249,3 +249,97 @@ def test_sah_tiers_and_megakernel(ctx, name):
     _check_tree(nodes, sid, qid, tid, scene)
     lb_img, lb_ids, _ = _gpu_render(ctx, scene, w, h, 1, bvh=abi.BVH_LBVH, tracer=abi.TRACER_MEGAKERNEL)
     assert np.array_equal(ids, lb_ids) and np.array_equal(img.view(np.uint32), lb_img.view(np.uint32))
+
+
+def _prim_bounds(scene):
+    """Exact (float64) bounds of every primitive, keyed by full primitive ID."""
+    out = {}
+    for i, s in enumerate(scene.spheres):
+        c, r = np.array(s["center"], np.float64), abs(float(s["radius"]))
+        out[(abi.KIND_SPHERE << 30) | i] = (c - r, c + r)
+    for i, q in enumerate(scene.quads):
+        c, u, v = (np.array(q[k], np.float64) for k in ("corner", "u", "v"))
+        pts = np.stack([c, c + u, c + v, c + u + v])
+        out[(abi.KIND_QUAD << 30) | i] = (pts.min(0), pts.max(0))
+    for i, t in enumerate(scene.tris):
+        pts = np.stack([np.array(t[k], np.float64) for k in ("v0", "v1", "v2")])
+        out[(abi.KIND_TRI << 30) | i] = (pts.min(0), pts.max(0))
+    return out
+
+
+def _check_wide(wide, levels, scene, sid, qid, tid):
+    """Structure of the 8-wide quantised BVH (bvh_wide.hip): every primitive in exactly one leaf slot, every slot's
+    decoded box (as real numbers) contains the exact bounds of everything beneath it, inner children consecutive."""
+    import sys
+    sys.setrecursionlimit(10000)
+    bounds = _prim_bounds(scene)
+    slot_ids = {abi.KIND_SPHERE: sid, abi.KIND_QUAD: qid, abi.KIND_TRI: tid}
+    seen = {}
+    max_depth = [0]
+
+    def visit(node, depth):
+        max_depth[0] = max(max_depth[0], depth)
+        w = wide[node]
+        hdr = w[:4]
+        origin = (hdr[:3] & np.uint32(0xFFFFFF00)).view(np.float32).astype(np.float64)
+        scale = np.ldexp(1.0, (hdr[:3] & np.uint32(0xFF)).astype(np.int64) - 127)
+        imask, base = int(hdr[3]) & 0xFF, int(hdr[3]) >> 8
+        q = w[4:16].view(np.uint8).reshape(6, 8).astype(np.float64)      # qlo x,y,z, qhi x,y,z per slot
+        lo_all, hi_all = None, None
+        for s in range(8):
+            link = int(w[16 + s])
+            qlo, qhi = q[0:3, s], q[3:6, s]
+            if (qlo > qhi).any():
+                assert link == 0xE0000000, f"node {node} slot {s}: empty box with link {link:#x}"
+                assert not (imask >> s) & 1
+                continue
+            blo, bhi = origin + qlo * scale, origin + qhi * scale
+            if (imask >> s) & 1:
+                child = base + bin(imask & ((1 << s) - 1)).count("1")
+                assert link == child
+                lo, hi = visit(child, depth + 1)
+            else:
+                assert link & 0x80000000
+                kind, cnt, first = (link >> 29) & 3, ((link >> 26) & 7) + 1, link & 0x3FFFFFF
+                lo, hi = None, None
+                for k in range(cnt):
+                    pid = int(slot_ids[kind][first + k])
+                    seen[pid] = seen.get(pid, 0) + 1
+                    plo, phi = bounds[pid]
+                    lo = plo if lo is None else np.minimum(lo, plo)
+                    hi = phi if hi is None else np.maximum(hi, phi)
+            assert (blo <= lo).all() and (bhi >= hi).all(), f"node {node} slot {s}: box does not contain its contents"
+            lo_all = lo if lo_all is None else np.minimum(lo_all, lo)
+            hi_all = hi if hi_all is None else np.maximum(hi_all, hi)
+        return lo_all, hi_all
+
+    visit(0, 1)
+    assert len(seen) == len(bounds) and all(v == 1 for v in seen.values())
+    assert max_depth[0] == levels
+    return max_depth[0]
+
+
+@pytest.mark.parametrize("bvh", [abi.BVH_LBVH | abi.BVH_WIDE, abi.BVH_SAH_REFINE | abi.BVH_WIDE], ids=["lbvh-wide", "sah-wide"])
+@pytest.mark.parametrize("name,w,h,n_iter", CASES + [("cirno", 96, 60, 2)])
+def test_wide_bvh_bit_exact(ctx, golden_dir, name, w, h, n_iter, bvh):
+    scene = abi.builtin_scene(name, w, h, golden_dir)
+    img, ids, ps = _gpu_render(ctx, scene, w, h, n_iter, bvh=bvh, tracer=abi.TRACER_WAVEFRONT)
+    ref_img, ref_ids, _ = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_FAST)
+    assert np.array_equal(ids, ref_ids)
+    assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32))
+    _, sid, qid, tid = ctx.bvh()
+    wide, levels = ctx.bvh_wide()
+    assert len(wide) > 0 and levels >= 1
+    _check_wide(wide, levels, scene, sid, qid, tid)
+
+
+def test_wide_single_primitive_and_pcg(ctx):
+    q = abi.builtin_scene("quads", 32, 32)
+    single = abi.HostScene(quads=q.quads[1:2], materials=q.materials, params=q.params)
+    img, ids, ps = _gpu_render(ctx, single, 32, 32, 2, bvh=abi.BVH_WIDE, tracer=abi.TRACER_WAVEFRONT)
+    ref_img, ref_ids, _ = orc.render(single, ps, 32, 32, flags=orc.TRAVERSE_BRUTE)
+    assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32)) and np.array_equal(ids, ref_ids)
+    scene = abi.builtin_scene("book1", 128, 72)
+    img, ids, ps = _gpu_render(ctx, scene, 128, 72, 3, bvh=abi.BVH_SAH_REFINE | abi.BVH_WIDE, rng_mode=abi.RNG_PCG, tracer=abi.TRACER_WAVEFRONT)
+    ref_img, ref_ids, _ = orc.render(scene, ps, 128, 72, flags=orc.TRAVERSE_FAST | orc.RNG_PCG)
+    assert np.array_equal(ids, ref_ids) and np.array_equal(img.view(np.uint32), ref_img.view(np.uint32))

@@ -1,5 +1,5 @@
 set -e
-for v in "lbvh 4" "collapse 4" "sah 1" "sah 2" "sah 4" "sah 8"; do
+for v in "sah 4" "lbvh-wide 4" "sah-wide 4"; do
   set -- $v
   echo "== bvh=$1 max_leaf=$2"
   CRT_BVH_MAX_LEAF=$2 timeout -k 10 120 python bench.py --no-cpu-baseline --steps 16 --warmup 2 --bvh $1 | python -c "

@@ -8,7 +8,7 @@ from computeraytracer_amd import abi
 import bench
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "lost_empire_4k"
-bvh = {"lbvh": abi.BVH_LBVH, "sah": abi.BVH_SAH_REFINE}[sys.argv[2] if len(sys.argv) > 2 else "sah"]
+bvh = {"lbvh": abi.BVH_LBVH, "sah": abi.BVH_SAH_REFINE, "sah-wide": abi.BVH_SAH_REFINE | abi.BVH_WIDE, "lbvh-wide": abi.BVH_WIDE}[sys.argv[2] if len(sys.argv) > 2 else "sah-wide"]
 scene_name, W, H, _ = bench.WORKLOADS[wl]
 scene = abi.builtin_scene(scene_name, W, H, os.path.join(ROOT, "tests", "golden"))
 ctx = abi.Context(0)
