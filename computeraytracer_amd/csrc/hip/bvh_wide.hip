@@ -8,7 +8,7 @@
 //
 // Node (128-byte stride, the first 64 bytes are what a traversal step loads):
 //   float4 0   {ox|ex, oy|ey, oz|ez, child_base<<8 | imask}
-//              o* = node origin as an fp32 with the low 8 mantissa bits cleared (rounded DOWN), e* = biased exponent
+//              o* = node origin as an fp32 with the low 9 mantissa bits cleared (rounded DOWN), e* = biased exponent
 //              of the per-axis grid step (2^(e-127)) in those low 8 bits; child_base = index of the first inner child
 //              (inner children are consecutive, in slot order); imask bit s = slot s is an inner node
 //   float4 1   {qlo_x[0..3], qlo_x[4..7], qlo_y[0..3], qlo_y[4..7]}      one byte per slot
@@ -88,13 +88,13 @@ __global__ __launch_bounds__(128) void k_wide_level(const float4 *pairs, uint32_
             c[best] = a;
             if (!pb) c[n++] = b;
         }
-        // node box, origin (rounded down to 16 mantissa bits) and per-axis grid step
+        // node box, origin (rounded down to 15 mantissa bits) and per-axis grid step
         float lo[3], hi[3], origin[3]; uint32_t ebits[3]; double scale[3];
         for (int a = 0; a < 3; a++) {
             lo[a] = c[0].lo[a]; hi[a] = c[0].hi[a];
             for (int k = 1; k < n; k++) { lo[a] = fminf(lo[a], c[k].lo[a]); hi[a] = fmaxf(hi[a], c[k].hi[a]); }
-            uint32_t b = __float_as_uint(lo[a]), t = b & 0xFFFFFF00u;
-            if ((b & 0x80000000u) && t != b) t += 0x100u;          // negative: truncation moved it up, step one unit down
+            uint32_t b = __float_as_uint(lo[a]), t = b & 0xFFFFFE00u;
+            if ((b & 0x80000000u) && t != b) t += 0x200u;          // negative: truncation moved it up, step one unit down
             origin[a] = __uint_as_float(t);
             const double ext = (double)hi[a] - (double)origin[a];
             int e = -100;

@@ -8,9 +8,11 @@
 //
 // Conservativeness.  The planes of a child box are the real numbers P = origin + q * 2^e.  A step evaluates
 // t = q * A + B with A = (1/d) * 2^e (exact) and B = fma(origin, 1/d, -(o * 1/d)); the rounding of 1/d, of o * 1/d,
-// of B and of the final fma moves t by at most 2^-23 |t| + 2^-24 (|o/d| + |B|).  Near planes therefore use
-// B - err, far planes (B + err) * (1 + 2^-20) with err = 2^-22 (|o/d| + |B|), and the far bound is the best hit
-// so far times (1 + 2^-18): a child whose true box the ray enters before the best hit is never culled.
+// of B and of the final fma moves t by at most 2^-23 |t| + 2^-24 (|o/d| + |B|), and |t| <= |B| + 255 |A| for every
+// plane of the node.  Near planes therefore use B - err, far planes B + err with
+// err = 2^-21 (|o/d| + |B| + 256 |A|) (four times the bound, which also absorbs the rounding of B -+ err), and the
+// far bound is the best hit so far times (1 + 2^-18): a child whose true box the ray enters before the best hit is
+// never culled.
 #pragma once
 #include "intersect.h"
 
@@ -65,31 +67,36 @@ CRT_DEV bool wide_advance(const float4 *nodes, WideTrav &tr, const uint2 *stack,
     return true;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 CRT_DEV float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }     // v_cvt_f32_ubyteK
+CRT_DEV f32x2 ubyte_f2(uint32_t w, int k) { f32x2 r; r.x = ubyte_f(w, k); r.y = ubyte_f(w, k + 1); return r; }
+CRT_DEV f32x2 splat2(float v) { f32x2 r; r.x = v; r.y = v; return r; }
+CRT_DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }        // v_pk_fma_f32
 
-// Inner step: tr.cur is a node index.
+// Node visit without the final wide_advance: tests the eight children of node tr.cur and makes them the top group.
 template <bool COUNT, bool SPILL>
-CRT_DEV bool wide_inner(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_t stack_stride, uint2 *spill, Counts &cnt) {
+CRT_DEV void wide_visit(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_t stack_stride, uint2 *spill, Counts &cnt) {
     const uint32_t node = tr.cur;
     const float4 *p = nodes + (size_t)kWideNodeF4 * node;
     const float4 h = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
     if (COUNT) cnt.nodes += 8;
     const uint32_t hx = f2u(h.x), hy = f2u(h.y), hz = f2u(h.z);
-    constexpr float kErr = 2.384185791015625e-07f;     // 2^-22
-    constexpr float kFar = 1.00000095367431640625f;    // 1 + 2^-20
-    // per-axis plane coefficients: t_near = q * an + bn, t_far = q * af + bf
-    const float ax = tr.idir.x * u2f((hx & 0xFFu) << 23), ay = tr.idir.y * u2f((hy & 0xFFu) << 23), az = tr.idir.z * u2f((hz & 0xFFu) << 23);
-    const float bx = __builtin_fmaf(u2f(hx & 0xFFFFFF00u), tr.idir.x, tr.noid.x);
-    const float by = __builtin_fmaf(u2f(hy & 0xFFFFFF00u), tr.idir.y, tr.noid.y);
-    const float bz = __builtin_fmaf(u2f(hz & 0xFFFFFF00u), tr.idir.z, tr.noid.z);
-    const float ex = (__builtin_fabsf(tr.noid.x) + __builtin_fabsf(bx)) * kErr;
-    const float ey = (__builtin_fabsf(tr.noid.y) + __builtin_fabsf(by)) * kErr;
-    const float ez = (__builtin_fabsf(tr.noid.z) + __builtin_fabsf(bz)) * kErr;
-    const float bnx = bx - ex, bny = by - ey, bnz = bz - ez;
-    const float afx = ax * kFar, afy = ay * kFar, afz = az * kFar;
-    const float bfx = (bx + ex) * kFar, bfy = (by + ey) * kFar, bfz = (bz + ez) * kFar;
+    constexpr float kErr = 4.76837158203125e-07f;      // 2^-21
+    // per-axis plane coefficients: t_near = q * a + bn, t_far = q * a + bf.  Bit 8 of a header word is zero, so
+    // word << 23 is the grid step 2^(e - 127) as a float.
+    const float ax = tr.idir.x * u2f(hx << 23), ay = tr.idir.y * u2f(hy << 23), az = tr.idir.z * u2f(hz << 23);
+    const float bx = __builtin_fmaf(u2f(hx & 0xFFFFFE00u), tr.idir.x, tr.noid.x);
+    const float by = __builtin_fmaf(u2f(hy & 0xFFFFFE00u), tr.idir.y, tr.noid.y);
+    const float bz = __builtin_fmaf(u2f(hz & 0xFFFFFE00u), tr.idir.z, tr.noid.z);
+    // |t| <= |b| + 255 |a| for every plane of this node, so err below covers the relative part of the error too
+    const float ex = __builtin_fmaf(__builtin_fabsf(ax), 256.0f, __builtin_fabsf(tr.noid.x) + __builtin_fabsf(bx)) * kErr;
+    const float ey = __builtin_fmaf(__builtin_fabsf(ay), 256.0f, __builtin_fabsf(tr.noid.y) + __builtin_fabsf(by)) * kErr;
+    const float ez = __builtin_fmaf(__builtin_fabsf(az), 256.0f, __builtin_fabsf(tr.noid.z) + __builtin_fabsf(bz)) * kErr;
+    const f32x2 ax2 = splat2(ax), ay2 = splat2(ay), az2 = splat2(az);
+    const f32x2 bnx = splat2(bx - ex), bny = splat2(by - ey), bnz = splat2(bz - ez);
+    const f32x2 bfx = splat2(bx + ex), bfy = splat2(by + ey), bfz = splat2(bz + ez);
     // near planes are the low ones for a non-negative direction component, the high ones otherwise
-    const bool nx = (tr.oct & 1u) != 0u, ny = (tr.oct & 2u) != 0u, nz = (tr.oct & 4u) != 0u;
+    const bool nx = (int32_t)f2u(tr.idir.x) < 0, ny = (int32_t)f2u(tr.idir.y) < 0, nz = (int32_t)f2u(tr.idir.z) < 0;
     const uint32_t lox[2] = {f2u(r1.x), f2u(r1.y)}, loy[2] = {f2u(r1.z), f2u(r1.w)}, loz[2] = {f2u(r2.x), f2u(r2.y)};
     const uint32_t hix[2] = {f2u(r2.z), f2u(r2.w)}, hiy[2] = {f2u(r3.x), f2u(r3.y)}, hiz[2] = {f2u(r3.z), f2u(r3.w)};
     uint32_t m = 0;
@@ -99,13 +106,16 @@ CRT_DEV bool wide_inner(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_
         const uint32_t qny = ny ? hiy[w] : loy[w], qfy = ny ? loy[w] : hiy[w];
         const uint32_t qnz = nz ? hiz[w] : loz[w], qfz = nz ? loz[w] : hiz[w];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float tnx = __builtin_fmaf(ubyte_f(qnx, k), ax, bnx), tfx = __builtin_fmaf(ubyte_f(qfx, k), afx, bfx);
-            const float tny = __builtin_fmaf(ubyte_f(qny, k), ay, bny), tfy = __builtin_fmaf(ubyte_f(qfy, k), afy, bfy);
-            const float tnz = __builtin_fmaf(ubyte_f(qnz, k), az, bnz), tfz = __builtin_fmaf(ubyte_f(qfz, k), afz, bfz);
-            const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
-            const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tr.tfar));
-            if (tn <= tf) m |= 1u << (4 * w + k);
+        for (int k = 0; k < 4; k += 2) {
+            const f32x2 tnx = fma2(ubyte_f2(qnx, k), ax2, bnx), tfx = fma2(ubyte_f2(qfx, k), ax2, bfx);
+            const f32x2 tny = fma2(ubyte_f2(qny, k), ay2, bny), tfy = fma2(ubyte_f2(qfy, k), ay2, bfy);
+            const f32x2 tnz = fma2(ubyte_f2(qnz, k), az2, bnz), tfz = fma2(ubyte_f2(qfz, k), az2, bfz);
+            const float tn0 = __builtin_fmaxf(__builtin_fmaxf(tnx.x, tny.x), __builtin_fmaxf(tnz.x, 0.0f));
+            const float tf0 = __builtin_fminf(__builtin_fminf(tfx.x, tfy.x), __builtin_fminf(tfz.x, tr.tfar));
+            const float tn1 = __builtin_fmaxf(__builtin_fmaxf(tnx.y, tny.y), __builtin_fmaxf(tnz.y, 0.0f));
+            const float tf1 = __builtin_fminf(__builtin_fminf(tfx.y, tfy.y), __builtin_fminf(tfz.y, tr.tfar));
+            if (tn0 <= tf0) m |= 1u << (4 * w + k);
+            if (tn1 <= tf1) m |= 1u << (4 * w + k + 1);
         }
     }
     if (m != 0u) {
@@ -123,6 +133,12 @@ CRT_DEV bool wide_inner(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_
         tr.g_hdr = f2u(h.w);
         tr.g_pend = (node << 8) | pm;
     }
+}
+
+// Inner step: tr.cur is a node index.
+template <bool COUNT, bool SPILL>
+CRT_DEV bool wide_inner(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_t stack_stride, uint2 *spill, Counts &cnt) {
+    wide_visit<COUNT, SPILL>(nodes, tr, stack, stack_stride, spill, cnt);
     return wide_advance<SPILL>(nodes, tr, stack, stack_stride, spill);
 }
 

@@ -156,7 +156,7 @@ bool launch_megakernel(hipStream_t stream, const DeviceSceneHost &sch, const Fra
 // owns exactly one path per dispatch) and appends survivors to the other queue with a wave ballot +
 // prefix count and a single atomic per wave on the sub-queue's own counter.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kShards = 64;
+constexpr uint32_t kShards = 256;
 constexpr uint32_t kMaxBounces = 16;
 constexpr uint32_t kCtrStride = 64;    // one counter per 256 bytes: neighbouring words share an L2 line and serialise their atomics
 constexpr uint32_t kFetchBatches = 4;  // at most this many 64-ray batches per work-fetch atomic
@@ -266,9 +266,10 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
     const float4 *ro = q.ray_o[bounce & 1], *rd = q.ray_d[bounce & 1];
     unsigned long long nodes = 0, prims = 0;
     unsigned long long c_iter = 0, c_inner = 0, c_inner_lanes = 0, c_leaf = 0, c_leaf_lanes = 0, c_refill = 0;     // COUNT only, wave-uniform
-    if (blockIdx.x == 0 && threadIdx.x < kShards) {
-        unsigned long long n = wave_sum((unsigned long long)counts[threadIdx.x * kCtrStride]);
-        if (threadIdx.x == 0) atomicAdd(&stats->rays, n - dead);
+    if (blockIdx.x == 0) {
+        static_assert(kShards <= 256, "one thread of block 0 per sub-queue");
+        unsigned long long n = wave_sum(threadIdx.x < kShards ? (unsigned long long)counts[threadIdx.x * kCtrStride] : 0ull);
+        if (lane == 0) atomicAdd(&stats->rays, n - (wave == 0 ? dead : 0ull));
     }
     if (sc.n_pairs == 0) {      // empty scene: every ray misses
         for (uint32_t s = 0; s < q.n_shards; s++) {
@@ -437,8 +438,8 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     if (f.max_bounces > kMaxBounces) { err = "wavefront tracer supports at most 16 bounces"; return false; }
     if (sch.n_pairs + 1 >= kMaxLeafLink) { err = "wavefront tracer supports at most 2^26 primitives"; return false; }
     WfQueues q;
-    static const uint32_t env_shards = [] { const char *e = getenv("CRT_WF_SHARDS"); int v = e ? atoi(e) : 16;
-                                            return (uint32_t)((v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? v : 16); }();
+    static const uint32_t env_shards = [] { const char *e = getenv("CRT_WF_SHARDS"); int v = e ? atoi(e) : 64;
+                                            return (uint32_t)((v >= 1 && v <= (int)kShards && (v & (v - 1)) == 0) ? v : 64); }();
     q.n_shards = env_shards;
     static const uint32_t env_precheck = [] { const char *e = getenv("CRT_WF_PRECHECK"); return (uint32_t)(e ? atoi(e) : 1); }();
     q.precheck = env_precheck;

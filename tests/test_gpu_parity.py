@@ -281,7 +281,7 @@ def _check_wide(wide, levels, scene, sid, qid, tid):
         max_depth[0] = max(max_depth[0], depth)
         w = wide[node]
         hdr = w[:4]
-        origin = (hdr[:3] & np.uint32(0xFFFFFF00)).view(np.float32).astype(np.float64)
+        origin = (hdr[:3] & np.uint32(0xFFFFFE00)).view(np.float32).astype(np.float64)
         scale = np.ldexp(1.0, (hdr[:3] & np.uint32(0xFF)).astype(np.int64) - 127)
         imask, base = int(hdr[3]) & 0xFF, int(hdr[3]) >> 8
         q = w[4:16].view(np.uint8).reshape(6, 8).astype(np.float64)      # qlo x,y,z, qhi x,y,z per slot
