@@ -36,6 +36,21 @@ WORKLOADS = {
     "grid10m_1080p": ("grid10m", 1920, 1080, "10M-triangle instanced grid, per-frame LBVH rebuild"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_JSON = os.path.join(ROOT, "profiles", "r01_pmc.json")   # tools/pmc_to_json.py over the rocprofv3 --pmc passes of this command
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (a separate rocprofv3 --pmc run of this
+    same command: counters cannot be read from inside the benchmark), or None."""
+    try:
+        ks = json.load(open(PMC_JSON))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    best = None
+    for name, d in ks.items():
+        if kernel_prefix in name and "hbm_traffic_bytes_per_dispatch" in d and (best is None or d["dispatches"] > best["dispatches"]):
+            best = d
+    return None if best is None else best["hbm_traffic_bytes_per_dispatch"]
 
 
 def cpu_baseline(scene, target_s=12.0):
@@ -47,10 +62,11 @@ def cpu_baseline(scene, target_s=12.0):
     small = abi.builtin_scene(scene.name, w, h, os.path.join(ROOT, "tests", "golden"))
     threads = min(orc.lib.orc_max_threads(), int(os.environ.get("OMP_NUM_THREADS", "16")))
     seeds = abi.frame_seeds(0, 2049)
+    orc.render(small, [small.params_for(1, seeds[0])], w, h, flags=orc.TRAVERSE_FAST, threads=threads, want_ids=False)   # warm: BVH, threads
     t0 = time.perf_counter()
-    _, _, c = orc.render(small, [small.params_for(1, seeds[0])], w, h, flags=orc.TRAVERSE_FAST, threads=threads, want_ids=False)
-    one = time.perf_counter() - t0
-    n = int(max(1, min(2048, target_s / max(one, 1e-3))))
+    _, _, c = orc.render(small, [small.params_for(i + 1, seeds[i]) for i in range(4)], w, h, flags=orc.TRAVERSE_FAST, threads=threads, want_ids=False)
+    one = (time.perf_counter() - t0) / 4
+    n = int(max(1, min(2048, target_s / max(one, 1e-4))))
     t0 = time.perf_counter()
     _, _, c = orc.render(small, [small.params_for(i + 2, seeds[i + 1]) for i in range(n)], w, h, flags=orc.TRAVERSE_FAST,
                          threads=threads, want_ids=False)
@@ -187,7 +203,8 @@ def main():
                        "bvh_build_ms": round(build_ms, 4), "gather_ms": None if gather_ms is None else round(gather_ms, 3),
                        "rays_per_path": round(D, 3), "nodes_per_ray": round(V, 2), "prim_tests_per_ray": round(T, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": pmc_traffic("k_wf_extend" if kernel_name == "k_wf_extend" else "k_megakernel") if args.workload == "lost_empire_4k" and world == 1 else None,
                          "kernel": kernel_name, "kernel_bytes_per_ray": round(kernel_bytes_per_ray, 1),
                          "pipeline_bytes_per_ray": round(bytes_per_ray, 1), "launch_ms": round(launch_ms, 4),
                          "launches": int(n_launches), "rays_per_launch": round(launch_rays)},

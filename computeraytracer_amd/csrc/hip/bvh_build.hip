@@ -71,14 +71,24 @@ __global__ void k_prim_bounds(BuildInput in, uint32_t n, float4 *plo, float4 *ph
         phi[g] = make_float4(hi[0], hi[1], hi[2], 0.0f);
         for (int a = 0; a < 3; a++) c[a] = 0.5f * lo[a] + 0.5f * hi[a];
     }
-    // wave-level min/max of the centroids, one atomic per wave and axis
+    // block-level min/max of the centroids (wave shuffles, then LDS), one atomic per block and axis: the six result
+    // words are a single hot line, so the number of atomics, not their width, sets this kernel's time
+    __shared__ uint32_t s_red[6][4];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int a = 0; a < 3; a++) {
         uint32_t mn = valid ? enc_f(c[a]) : 0xFFFFFFFFu, mx = valid ? enc_f(c[a]) : 0u;
         for (int off = 32; off > 0; off >>= 1) {
             mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
             mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
         }
-        if ((threadIdx.x & 63) == 0) { atomicMin(&scene_bounds[a], mn); atomicMax(&scene_bounds[3 + a], mx); }
+        if (lane == 0) { s_red[a][wave] = mn; s_red[3 + a][wave] = mx; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const uint32_t nw = (blockDim.x + 63) / 64;
+        uint32_t v = s_red[threadIdx.x][0];
+        for (uint32_t w = 1; w < nw; w++) v = threadIdx.x < 3 ? min(v, s_red[threadIdx.x][w]) : max(v, s_red[threadIdx.x][w]);
+        if (threadIdx.x < 3) atomicMin(&scene_bounds[threadIdx.x], v); else atomicMax(&scene_bounds[threadIdx.x], v);
     }
 }
 
