@@ -224,63 +224,117 @@ __device__ __forceinline__ void write_child(float4 *pair_half, int n, uint32_t c
     pair_half[1] = make_float4(hi.x, hi.y, hi.z, __uint_as_float(count));
 }
 
-// Bottom-up refit.  One thread per leaf climbs; at each inner node the first arrival stops, the second
-// (which therefore knows both subtrees are finished) computes the node.  Cross-workgroup hand-off of
-// the sibling's data: stores, agent-scope fence (release), returning atomic; the winner fences again
-// (acquire: invalidates this CU's L1) before loading what the other thread stored.
+// Bottom-up refit.  A climber starts at a finished node; at each inner node the first arrival stops, the second
+// (which therefore knows both subtrees are finished) computes the node and climbs on.  Hand-off of the sibling's
+// data: stores, release fence, returning atomic; the winner fences again (acquire) before loading what the other
+// climber stored.  The SCOPE of that hand-off is what this costs: an agent-scope release writes this XCD's L2
+// back (the eight L2s are not coherent with each other), and with one such fence per thread and level a
+// 10 M-triangle refit took 79 ms (47 ms with agent scope only on the ~4 % of nodes that span a workgroup boundary).
+// So the refit runs in stages and never leaves workgroup scope:
+//   stage 1   a workgroup owns 256 consecutive leaves and climbs while the parent's range stays inside them: both
+//             climbers of such a node are waves of this workgroup, on one CU behind one L1.  A climber whose parent
+//             reaches outside parks its (finished) node in the workgroup's continuation list;
+//   stage s   a workgroup owns 64 ranges of stage s-1, resumes their parked climbers and climbs while the parent
+//             stays inside its 64x larger range.  The kernel boundary between stages makes the earlier stores visible.
+// A range of the sorted leaves decomposes into at most 2 * depth maximal subtrees and the tree is at most 62 deep
+// (30 Morton bits + 32 index bits of tie-break), so a list of 256 entries per workgroup cannot overflow.
 //
-// SAH leaf collapse (CRT_BVH_SAH_REFINE): with C(leaf of n) = Ci * n * A and C(inner) = Ct * A + C(left) + C(right)
+// SAH leaf collapse (CRT_BVH_LEAF_COLLAPSE): with C(leaf of n) = Ci * n * A and C(inner) = Ct * A + C(left) + C(right)
 // (A = surface area; entering a node costs one pair fetch + two slab tests = Ct), a subtree of one kind with at most
 // max_leaf primitives becomes a single leaf when that is not more expensive.  Its primitives are contiguous in the
 // sorted arrays because an LBVH subtree covers a contiguous Morton range.
-__global__ void k_refit_emit(int n, const uint32_t *vals, const float4 *plo, const float4 *phi,
-                             const uint32_t *child_l, const uint32_t *child_r, const uint32_t *parent,
-                             const uint32_t *leaf_link, const uint32_t *leaf_count,
-                             float4 *nlo, float4 *nhi, float4 *ninfo, uint32_t *flags, float4 *pairs,
-                             uint32_t max_leaf, float c_isect, float c_trav) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    uint32_t node = (uint32_t)(n - 1 + j);
-    uint32_t g = vals[j];
-    float4 lo = plo[g], hi = phi[g];
-    Sub sub;
-    sub.count = 1; sub.kind_flags = leaf_count[j] >> 28; sub.first = (uint32_t)j;
-    sub.cost = c_isect * half_area(lo, hi);
-    nlo[node] = lo; nhi[node] = hi; ninfo[node] = sub_pack(sub);
+constexpr uint32_t kRefitLeaves = 256;     // leaves per stage-1 workgroup
+constexpr uint32_t kRefitFan = 64;         // ranges of the previous stage per workgroup of a later stage
+constexpr uint32_t kRefitCap = 256;        // continuation entries per workgroup
+
+struct RefitArgs {
+    int n;
+    const uint32_t *vals; const float4 *plo, *phi;
+    const uint32_t *child_l, *child_r, *parent, *range_lo, *range_hi, *leaf_link, *leaf_count;
+    float4 *nlo, *nhi, *ninfo; uint32_t *flags; float4 *pairs;
+    uint32_t max_leaf; float c_isect, c_trav;
+};
+
+__device__ __forceinline__ void refit_climb(const RefitArgs &A, uint32_t node, float4 lo, float4 hi, Sub sub,
+                                            uint32_t blk_lo, uint32_t blk_hi, uint32_t *s_count, uint32_t *list_out) {
+    const int n = A.n;
     for (;;) {
-        uint32_t p = parent[node];
-        if (p == 0xFFFFFFFFu) break;
-        __threadfence();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        uint32_t old = atomicAdd(&flags[p], 1u);
-        if (old == 0u) break;
-        __threadfence();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        uint32_t cl = child_l[p], cr = child_r[p];
-        uint32_t sib = cl == node ? cr : cl;
-        float4 slo = nlo[sib], shi = nhi[sib];
-        Sub ssub = sub_unpack(ninfo[sib]);
-        bool mine_left = cl == node;
-        float4 l_lo = mine_left ? lo : slo, l_hi = mine_left ? hi : shi;
-        float4 r_lo = mine_left ? slo : lo, r_hi = mine_left ? shi : hi;
-        Sub l_sub = mine_left ? sub : ssub, r_sub = mine_left ? ssub : sub;
-        write_child(pairs + 4 * (size_t)p, n, cl, l_lo, l_hi, l_sub, leaf_link);
-        write_child(pairs + 4 * (size_t)p + 2, n, cr, r_lo, r_hi, r_sub, leaf_link);
+        const uint32_t p = A.parent[node];
+        if (p == 0xFFFFFFFFu) return;                                  // node is the root
+        if (A.range_lo[p] < blk_lo || A.range_hi[p] > blk_hi) {        // the parent belongs to a later stage
+            const uint32_t k = atomicAdd(s_count, 1u);
+            if (k < kRefitCap) list_out[k] = node;
+            return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const uint32_t old = __hip_atomic_fetch_add(&A.flags[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (old == 0u) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t cl = A.child_l[p], cr = A.child_r[p];
+        const uint32_t sib = cl == node ? cr : cl;
+        const float4 slo = A.nlo[sib], shi = A.nhi[sib];
+        const Sub ssub = sub_unpack(A.ninfo[sib]);
+        const bool mine_left = cl == node;
+        const float4 l_lo = mine_left ? lo : slo, l_hi = mine_left ? hi : shi;
+        const float4 r_lo = mine_left ? slo : lo, r_hi = mine_left ? shi : hi;
+        const Sub l_sub = mine_left ? sub : ssub, r_sub = mine_left ? ssub : sub;
+        write_child(A.pairs + 4 * (size_t)p, n, cl, l_lo, l_hi, l_sub, A.leaf_link);
+        write_child(A.pairs + 4 * (size_t)p + 2, n, cr, r_lo, r_hi, r_sub, A.leaf_link);
         lo = make_float4(fminf(l_lo.x, r_lo.x), fminf(l_lo.y, r_lo.y), fminf(l_lo.z, r_lo.z), 0.0f);
         hi = make_float4(fmaxf(l_hi.x, r_hi.x), fmaxf(l_hi.y, r_hi.y), fmaxf(l_hi.z, r_hi.z), 0.0f);
-        float area = half_area(lo, hi);
-        uint32_t lk = l_sub.kind_flags & 0xFFu, rk = r_sub.kind_flags & 0xFFu;
+        const float area = half_area(lo, hi);
+        const uint32_t lk = l_sub.kind_flags & 0xFFu, rk = r_sub.kind_flags & 0xFFu;
         sub.count = l_sub.count + r_sub.count;
         sub.first = l_sub.first;                       // the left child covers the lower part of the range
-        uint32_t kind = (lk == rk) ? lk : kMixed;
-        float as_inner = c_trav * area + l_sub.cost + r_sub.cost;
-        float as_leaf = c_isect * (float)sub.count * area;
-        bool collapse = kind != kMixed && sub.count <= max_leaf && as_leaf <= as_inner;
+        const uint32_t kind = (lk == rk) ? lk : kMixed;
+        const float as_inner = A.c_trav * area + l_sub.cost + r_sub.cost;
+        const float as_leaf = A.c_isect * (float)sub.count * area;
+        const bool collapse = kind != kMixed && sub.count <= A.max_leaf && as_leaf <= as_inner;
         sub.cost = collapse ? as_leaf : as_inner;
         sub.kind_flags = kind | (collapse ? kCollapsed : 0u);
-        nlo[p] = lo; nhi[p] = hi; ninfo[p] = sub_pack(sub);
+        A.nlo[p] = lo; A.nhi[p] = hi; A.ninfo[p] = sub_pack(sub);
         node = p;
     }
+}
+
+// Stage 1: one thread per leaf.
+__global__ __launch_bounds__(kRefitLeaves) void k_refit_leaves(RefitArgs A, uint32_t *list_out, uint32_t *count_out) {
+    __shared__ uint32_t s_count;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    const uint32_t j = blockIdx.x * kRefitLeaves + threadIdx.x;
+    if (j < (uint32_t)A.n) {
+        const uint32_t node = (uint32_t)(A.n - 1) + j;
+        const uint32_t g = A.vals[j];
+        const float4 lo = A.plo[g], hi = A.phi[g];
+        Sub sub;
+        sub.count = 1; sub.kind_flags = A.leaf_count[j] >> 28; sub.first = j;
+        sub.cost = A.c_isect * half_area(lo, hi);
+        A.nlo[node] = lo; A.nhi[node] = hi; A.ninfo[node] = sub_pack(sub);
+        const uint32_t blk_lo = blockIdx.x * kRefitLeaves;
+        refit_climb(A, node, lo, hi, sub, blk_lo, blk_lo + kRefitLeaves - 1u, &s_count, list_out + (size_t)blockIdx.x * kRefitCap);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) count_out[blockIdx.x] = min(s_count, kRefitCap);
+}
+
+// Later stages: workgroup b resumes the climbers parked by workgroups [b * kRefitFan, (b + 1) * kRefitFan) of the
+// previous stage; `range` = leaves per workgroup of THIS stage.
+__global__ __launch_bounds__(1024) void k_refit_resume(RefitArgs A, uint32_t n_prev, const uint32_t *list_in, const uint32_t *count_in,
+                                                       uint32_t range, uint32_t *list_out, uint32_t *count_out) {
+    __shared__ uint32_t s_count;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    const uint32_t blk_lo = blockIdx.x * range, blk_hi = blk_lo + (range - 1u);
+    for (uint32_t e = threadIdx.x; e < kRefitFan * kRefitCap; e += blockDim.x) {
+        const uint32_t sb = blockIdx.x * kRefitFan + e / kRefitCap, k = e % kRefitCap;
+        if (sb >= n_prev || k >= count_in[sb]) continue;
+        const uint32_t node = list_in[(size_t)sb * kRefitCap + k];
+        refit_climb(A, node, A.nlo[node], A.nhi[node], sub_unpack(A.ninfo[node]), blk_lo, blk_hi, &s_count,
+                    list_out + (size_t)blockIdx.x * kRefitCap);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) count_out[blockIdx.x] = min(s_count, kRefitCap);
 }
 
 // n == 1: a single leaf beside an empty leaf (count field = kind bits only, zero primitives).
@@ -373,10 +427,10 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     const bool sah = (flags & CRT_BVH_SAH_REFINE) != 0 && n >= 2;
     const uint32_t *order = vals;
     if (n >= 2) {
-        if (sah && (!ensure(st.range_lo, (size_t)n * 4, err) || !ensure(st.range_hi, (size_t)n * 4, err))) return false;
+        if (!ensure(st.range_lo, (size_t)n * 4, err) || !ensure(st.range_hi, (size_t)n * 4, err)) return false;
         hipLaunchKernelGGL(k_hierarchy, dim3((n - 1 + 255) / 256), dim3(256), 0, stream, (int)n, keys, (uint32_t *)st.child_l.ptr,
-                           (uint32_t *)st.child_r.ptr, (uint32_t *)st.parent.ptr, sah ? (uint32_t *)st.range_lo.ptr : nullptr,
-                           sah ? (uint32_t *)st.range_hi.ptr : nullptr);
+                           (uint32_t *)st.child_r.ptr, (uint32_t *)st.parent.ptr, (uint32_t *)st.range_lo.ptr,
+                           (uint32_t *)st.range_hi.ptr);
         HIP_TRY(hipGetLastError());
     }
     if (sah) {
@@ -410,11 +464,31 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
         return wide ? build_wide(stream, st, err) : true;
     }
     HIP_TRY(hipMemsetAsync(st.flag_a.ptr, 0, (size_t)n * 4, stream));
-    hipLaunchKernelGGL(k_refit_emit, dim3(blocks), dim3(256), 0, stream, (int)n, vals, (const float4 *)st.plo.ptr,
-                       (const float4 *)st.phi.ptr, (const uint32_t *)st.child_l.ptr, (const uint32_t *)st.child_r.ptr,
-                       (const uint32_t *)st.parent.ptr, (const uint32_t *)st.leaf_link.ptr, (const uint32_t *)st.leaf_count.ptr,
-                       (float4 *)st.nlo.ptr, (float4 *)st.nhi.ptr, (float4 *)st.ninfo.ptr, (uint32_t *)st.flag_a.ptr, (float4 *)st.pairs.ptr,
-                       (flags & CRT_BVH_LEAF_COLLAPSE) ? (st.max_leaf < 1u ? 1u : st.max_leaf > 8u ? 8u : st.max_leaf) : 1u, st.c_isect, st.c_trav);
+    RefitArgs ra;
+    ra.n = (int)n; ra.vals = vals; ra.plo = (const float4 *)st.plo.ptr; ra.phi = (const float4 *)st.phi.ptr;
+    ra.child_l = (const uint32_t *)st.child_l.ptr; ra.child_r = (const uint32_t *)st.child_r.ptr; ra.parent = (const uint32_t *)st.parent.ptr;
+    ra.range_lo = (const uint32_t *)st.range_lo.ptr; ra.range_hi = (const uint32_t *)st.range_hi.ptr;
+    ra.leaf_link = (const uint32_t *)st.leaf_link.ptr; ra.leaf_count = (const uint32_t *)st.leaf_count.ptr;
+    ra.nlo = (float4 *)st.nlo.ptr; ra.nhi = (float4 *)st.nhi.ptr; ra.ninfo = (float4 *)st.ninfo.ptr;
+    ra.flags = (uint32_t *)st.flag_a.ptr; ra.pairs = (float4 *)st.pairs.ptr;
+    ra.max_leaf = (flags & CRT_BVH_LEAF_COLLAPSE) ? (st.max_leaf < 1u ? 1u : st.max_leaf > 8u ? 8u : st.max_leaf) : 1u;
+    ra.c_isect = st.c_isect; ra.c_trav = st.c_trav;
+    // continuation lists of two consecutive stages (ping-pong); stage 1 has the most workgroups
+    uint32_t n_wg = (n + kRefitLeaves - 1) / kRefitLeaves;
+    const uint32_t n_wg2 = (n_wg + kRefitFan - 1) / kRefitFan;
+    if (!ensure(st.refit_list[0], (size_t)n_wg * kRefitCap * 4, err) || !ensure(st.refit_count[0], (size_t)n_wg * 4, err)) return false;
+    if (!ensure(st.refit_list[1], (size_t)n_wg2 * kRefitCap * 4, err) || !ensure(st.refit_count[1], (size_t)n_wg2 * 4, err)) return false;
+    hipLaunchKernelGGL(k_refit_leaves, dim3(n_wg), dim3(kRefitLeaves), 0, stream, ra, (uint32_t *)st.refit_list[0].ptr, (uint32_t *)st.refit_count[0].ptr);
+    uint64_t range = kRefitLeaves;
+    for (int cur = 0; n_wg > 1; cur ^= 1) {
+        const uint32_t n_prev = n_wg;
+        n_wg = (n_wg + kRefitFan - 1) / kRefitFan;
+        range *= kRefitFan;
+        // the last stage's range covers every leaf, so nothing is parked there
+        hipLaunchKernelGGL(k_refit_resume, dim3(n_wg), dim3(1024), 0, stream, ra, n_prev, (const uint32_t *)st.refit_list[cur].ptr,
+                           (const uint32_t *)st.refit_count[cur].ptr, (uint32_t)std::min<uint64_t>(range, 0x80000000ull),
+                           (uint32_t *)st.refit_list[cur ^ 1].ptr, (uint32_t *)st.refit_count[cur ^ 1].ptr);
+    }
     HIP_TRY(hipGetLastError());
     return wide ? build_wide(stream, st, err) : true;
 }
@@ -424,7 +498,8 @@ void free_build_state(BuildState &st) {
                            &st.rank_b, &st.leaf_link, &st.leaf_count, &st.child_l, &st.child_r, &st.parent, &st.nlo, &st.nhi, &st.ninfo,
                            &st.scene_bounds, &st.temp, &st.range_lo, &st.range_hi, &st.sah_flag, &st.sah_ipos[0],
                            &st.sah_ipos[1], &st.sah_starts, &st.sah_desc, &st.perm, &st.pairs, &st.tri_pack, &st.sphere_pack, &st.quad_pack, &st.sphere_ids,
-                           &st.quad_ids, &st.tri_ids, &st.wide, &st.wide_queue[0], &st.wide_queue[1], &st.wide_levels_dev};
+                           &st.quad_ids, &st.tri_ids, &st.wide, &st.wide_queue[0], &st.wide_queue[1], &st.wide_levels_dev,
+                           &st.refit_list[0], &st.refit_list[1], &st.refit_count[0], &st.refit_count[1]};
     for (DeviceBuffer *b : all) if (b->ptr) { hipError_t e = hipFree(b->ptr); (void)e; b->ptr = nullptr; b->bytes = 0; }
 }
 
