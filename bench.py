@@ -25,6 +25,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # PyTorch-ROCm bundles its own HIP runtime (same soname as /opt/rocm's).  Loaded first, libcrt.so binds to that one
+    # copy; loaded second, the process ends up with two runtimes and the second cannot open the GPU.
+    import torch  # noqa: F401,E402
+
 from computeraytracer_amd import abi  # noqa: E402
 
 WORKLOADS = {
@@ -51,6 +56,29 @@ def pmc_traffic(kernel_prefix):
         if kernel_prefix in name and "hbm_traffic_bytes_per_dispatch" in d and (best is None or d["dispatches"] > best["dispatches"]):
             best = d
     return None if best is None else best["hbm_traffic_bytes_per_dispatch"]
+
+
+def parity_sample(scene, tracer, bvh_flags, device):
+    """RMSE / primary-hit-ID check of the GPU path against the CPU oracle on a small sample of the bench scene (the
+    metric names "RMSE vs ref"; the parity tests proper are tests/test_gpu_parity.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc   # the checker, never the product
+    w, h, n = 256, 144, 4
+    small = abi.builtin_scene(scene.name, w, h, os.path.join(ROOT, "tests", "golden"))
+    seeds = abi.frame_seeds(0, n)
+    ps = [small.params_for(i + 1, seeds[i]) for i in range(n)]
+    ref_img, ref_ids, _ = orc.render(small, ps, w, h, flags=orc.TRAVERSE_FAST)
+    with abi.Context(device) as c:
+        c.configure(w, h, tracer=tracer)
+        c.upload(small); c.build(bvh_flags)
+        c.render(ps[0], 1, seeds); c.sync()
+        img, ids = c.image(), c.hit_ids()
+    a = img[..., :3] / np.maximum(img[..., 3:4], 1.0)
+    b = ref_img[..., :3] / np.maximum(ref_img[..., 3:4], 1.0)
+    return {"rmse": float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))),
+            "primary_id_mismatches": int((ids != ref_ids).sum()),
+            "bit_exact": bool(np.array_equal(img.view(np.uint32), ref_img.view(np.uint32))),
+            "sample": f"{small.name} {w}x{h} x {n} iterations vs the CPU oracle"}
 
 
 def cpu_baseline(scene, target_s=12.0):
@@ -91,11 +119,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # CRT_BENCH_REHEARSE=1: every rank on GPU 0 and gloo instead of RCCL, to rehearse the multi-rank path of this script
+    # on a one-GPU box (RCCL refuses two ranks on one device); never set by the driver
+    rehearse = os.environ.get("CRT_BENCH_REHEARSE", "") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     scene_name, W, H, label = WORKLOADS[args.workload]
     scene = abi.builtin_scene(scene_name, W, H, os.path.join(ROOT, "tests", "golden"))
@@ -159,14 +195,15 @@ def main():
     gather_ms = None
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed, rays], dtype=torch.float64, device="cuda")
+        tdev = torch.device("cpu") if rehearse else torch.device("cuda", local_rank)
+        t = torch.tensor([elapsed, rays], dtype=torch.float64, device=tdev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed, rays = float(tmax[0]), float(t[1])
         # gather the finished image: one all-gather of the packed band buffers + un-interleave (dist.py)
         from computeraytracer_amd import dist as cdist
-        band = cdist.context_band_tensor(ctx, W, torch.device("cuda", local_rank))
+        band = cdist.context_band_tensor(ctx, W, torch.device("cuda", local_rank)).to(tdev)
         torch.cuda.synchronize(); dist.barrier()
         g0 = time.perf_counter()
         image = cdist.gather_image(band, H, world)
@@ -211,6 +248,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene)
+            line["parity"] = parity_sample(scene, tracer, bvh_flags, local_rank)
         print(json.dumps(line), flush=True)
     ctx.close()
     if dist is not None:

@@ -5,6 +5,10 @@ b % world == rank (crt_config.band_rank / band_world); pixels are independent gi
 the global pixel position, so the partition does not change any pixel.  The only exchange step is one all-gather of the
 packed band buffers (RCCL over xGMI on GPUs, gloo on CPU in the tests) after the last iteration, followed by an
 un-interleave.  torch / torch.distributed are used for that plumbing only.
+
+A process that uses both must `import torch` BEFORE computeraytracer_amd.abi loads libcrt.so: PyTorch-ROCm ships its own
+HIP runtime under the same soname, the first one loaded is the one both share, and libcrt.so loaded first leaves the
+process with two runtimes of which the second cannot open the GPU (crt_create then reports "no usable HIP device").
 """
 import numpy as np
 
