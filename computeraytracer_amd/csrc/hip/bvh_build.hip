@@ -4,7 +4,7 @@
 //
 // Pipeline (all on the context's stream, no host round trips):
 //   1. k_prim_bounds   padded AABB + centroid per primitive, scene centroid bounds (atomic min/max)
-//   2. k_morton        30-bit Morton code of the centroid
+//   2. k_morton        Morton code of the centroid, 10..21 bits per axis by primitive count (64-bit keys)
 //   3. radix sort      (code, primitive) pairs, rocPRIM
 //   4. kind ranks      exclusive scans of "is sphere" / "is quad" over the sorted order, rocPRIM
 //   5. k_pack          traversal records per kind in sorted order (tri 48 B, sphere 16 B, quad 64 B)
@@ -45,11 +45,12 @@ __device__ __forceinline__ void prim_box(const BuildInput &in, uint32_t g, float
             hi[a] = fmaxf(fmaxf(c, cu), fmaxf(cv, cuv));
         }
     } else {
-        const crt_tri &t = in.tris[g - in.n_spheres - in.n_quads];
-        for (int a = 0; a < 3; a++) {
-            lo[a] = fminf(fminf(t.v0[a], t.v1[a]), t.v2[a]);
-            hi[a] = fmaxf(fmaxf(t.v0[a], t.v1[a]), t.v2[a]);
-        }
+        // three 16-byte loads (v0, v1, v2 rows of the 96-byte record) instead of nine strided dwords
+        const float4 *p = (const float4 *)(in.tris + (g - in.n_spheres - in.n_quads));
+        const float4 v0 = p[0], v1 = p[1], v2 = p[2];
+        lo[0] = fminf(fminf(v0.x, v1.x), v2.x); hi[0] = fmaxf(fmaxf(v0.x, v1.x), v2.x);
+        lo[1] = fminf(fminf(v0.y, v1.y), v2.y); hi[1] = fmaxf(fmaxf(v0.y, v1.y), v2.y);
+        lo[2] = fminf(fminf(v0.z, v1.z), v2.z); hi[2] = fmaxf(fmaxf(v0.z, v1.z), v2.z);
     }
     // Conservative padding: the slab test runs in fma form with rounded -o/d terms (intersect.h); 2^-18
     // of the coordinate magnitude is ~64 ulp, far above its error, far below any feature size.
@@ -92,28 +93,34 @@ __global__ void k_prim_bounds(BuildInput in, uint32_t n, float4 *plo, float4 *ph
     }
 }
 
-__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
+// Spread the low 21 bits of v to every third bit.
+__device__ __forceinline__ uint64_t expand_bits21(uint64_t v) {
+    v &= 0x1FFFFFull;
+    v = (v | v << 32) & 0x1F00000000FFFFull;
+    v = (v | v << 16) & 0x1F0000FF0000FFull;
+    v = (v | v << 8) & 0x100F00F00F00F00Full;
+    v = (v | v << 4) & 0x10C30C30C30C30C3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
     return v;
 }
 
-__global__ void k_morton(uint32_t n, const float4 *plo, const float4 *phi, const uint32_t *scene_bounds,
-                         uint32_t *keys, uint32_t *vals) {
+// Morton code of the centroid, `bits` per axis (10..21, chosen from the primitive count: cells finer than the
+// primitives' spacing keep equal codes, which the hierarchy can only split by index, rare).
+__global__ void k_morton(uint32_t n, uint32_t bits, const float4 *plo, const float4 *phi, const uint32_t *scene_bounds,
+                         uint64_t *keys, uint32_t *vals) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
     float4 lo = plo[g], hi = phi[g];
     float c[3] = {0.5f * lo.x + 0.5f * hi.x, 0.5f * lo.y + 0.5f * hi.y, 0.5f * lo.z + 0.5f * hi.z};
-    uint32_t q[3];
+    const float cells = (float)(1u << bits);
+    uint64_t q[3];
     for (int a = 0; a < 3; a++) {
         float mn = dec_f(scene_bounds[a]), mx = dec_f(scene_bounds[3 + a]);
         float ext = mx - mn;
         float f = ext > 0.0f ? (c[a] - mn) / ext : 0.0f;
-        q[a] = (uint32_t)fminf(fmaxf(f * 1024.0f, 0.0f), 1023.0f);
+        q[a] = (uint64_t)fminf(fmaxf(f * cells, 0.0f), cells - 1.0f);
     }
-    keys[g] = (expand_bits10(q[0]) << 2) | (expand_bits10(q[1]) << 1) | expand_bits10(q[2]);
+    keys[g] = (expand_bits21(q[0]) << 2) | (expand_bits21(q[1]) << 1) | expand_bits21(q[2]);
     vals[g] = g;
 }
 
@@ -151,12 +158,13 @@ __global__ void k_pack(BuildInput in, uint32_t n, const uint32_t *vals, const ui
     } else {
         uint32_t i = g - in.n_spheres - in.n_quads;
         uint32_t rt = s - rs - rq;
-        const crt_tri &t = in.tris[i];
+        const float4 *tp = (const float4 *)(in.tris + i);
+        const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
         // e10 = v1 - v0, e20 = v2 - v0: the same two IEEE subtractions hit_tri performs (compute.comp:281-282)
-        float e1x = t.v1[0] - t.v0[0], e1y = t.v1[1] - t.v0[1], e1z = t.v1[2] - t.v0[2];
-        float e2x = t.v2[0] - t.v0[0], e2y = t.v2[1] - t.v0[1], e2z = t.v2[2] - t.v0[2];
+        float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
+        float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
         float4 *o = tri_pack + 3 * (size_t)rt;
-        o[0] = make_float4(t.v0[0], t.v0[1], t.v0[2], e1x);
+        o[0] = make_float4(v0.x, v0.y, v0.z, e1x);
         o[1] = make_float4(e1y, e1z, e2x, e2y);
         o[2] = make_float4(e2z, __uint_as_float(CRT_MAKE_ID(CRT_ID_KIND_TRI, i)), 0.0f, 0.0f);
         tri_ids[rt] = i;
@@ -165,15 +173,15 @@ __global__ void k_pack(BuildInput in, uint32_t n, const uint32_t *vals, const ui
 }
 
 // delta(i, j): length of the common prefix of keys i and j, ties broken by the index (Karras 2012, section 4).
-__device__ __forceinline__ int delta(const uint32_t *keys, int n, int i, int j) {
+__device__ __forceinline__ int delta(const uint64_t *keys, int n, int i, int j) {
     if (j < 0 || j >= n) return -1;
-    uint32_t a = keys[i], b = keys[j];
-    if (a == b) return 32 + __clz((uint32_t)i ^ (uint32_t)j);
-    return __clz(a ^ b);
+    uint64_t a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((uint32_t)i ^ (uint32_t)j);
+    return __clzll((long long)(a ^ b));
 }
 
 // Node numbering: inner i in [0, n-2], leaf j -> (n - 1) + j.  parent[] is indexed by that numbering.
-__global__ void k_hierarchy(int n, const uint32_t *keys, uint32_t *child_l, uint32_t *child_r, uint32_t *parent,
+__global__ void k_hierarchy(int n, const uint64_t *keys, uint32_t *child_l, uint32_t *child_r, uint32_t *parent,
                             uint32_t *range_lo, uint32_t *range_hi) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
@@ -236,8 +244,8 @@ __device__ __forceinline__ void write_child(float4 *pair_half, int n, uint32_t c
 //             reaches outside parks its (finished) node in the workgroup's continuation list;
 //   stage s   a workgroup owns 64 ranges of stage s-1, resumes their parked climbers and climbs while the parent
 //             stays inside its 64x larger range.  The kernel boundary between stages makes the earlier stores visible.
-// A range of the sorted leaves decomposes into at most 2 * depth maximal subtrees and the tree is at most 62 deep
-// (30 Morton bits + 32 index bits of tie-break), so a list of 256 entries per workgroup cannot overflow.
+// A range of the sorted leaves decomposes into at most 2 * depth maximal subtrees and the tree is at most 95 deep
+// (up to 63 Morton bits + 32 index bits of tie-break), so a list of 256 entries per workgroup cannot overflow.
 //
 // SAH leaf collapse (CRT_BVH_LEAF_COLLAPSE): with C(leaf of n) = Ci * n * A and C(inner) = Ct * A + C(left) + C(right)
 // (A = surface area; entering a node costs one pair fetch + two slab tests = Ct), a subtree of one kind with at most
@@ -326,9 +334,11 @@ __global__ __launch_bounds__(1024) void k_refit_resume(RefitArgs A, uint32_t n_p
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
     const uint32_t blk_lo = blockIdx.x * range, blk_hi = blk_lo + (range - 1u);
-    for (uint32_t e = threadIdx.x; e < kRefitFan * kRefitCap; e += blockDim.x) {
-        const uint32_t sb = blockIdx.x * kRefitFan + e / kRefitCap, k = e % kRefitCap;
-        if (sb >= n_prev || k >= count_in[sb]) continue;
+    // 16 threads per previous-stage range (a range parks ~2 log2(its size) climbers, so usually one pass)
+    static_assert(kRefitFan * 16 == 1024, "one 16-thread group per previous-stage range");
+    const uint32_t sb = blockIdx.x * kRefitFan + threadIdx.x / 16u;
+    const uint32_t cnt = sb < n_prev ? count_in[sb] : 0u;
+    for (uint32_t k = threadIdx.x % 16u; k < cnt; k += 16u) {
         const uint32_t node = list_in[(size_t)sb * kRefitCap + k];
         refit_climb(A, node, A.nlo[node], A.nhi[node], sub_unpack(A.ninfo[node]), blk_lo, blk_hi, &s_count,
                     list_out + (size_t)blockIdx.x * kRefitCap);
@@ -388,8 +398,8 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     const uint32_t blocks = (n + 255) / 256;
     const size_t n4 = (size_t)n * sizeof(float4);
     if (!ensure(st.plo, n4, err) || !ensure(st.phi, n4, err)) return false;
-    if (!ensure(st.keys, (size_t)n * 4, err) || !ensure(st.vals, (size_t)n * 4, err)) return false;
-    if (!ensure(st.keys_alt, (size_t)n * 4, err) || !ensure(st.vals_alt, (size_t)n * 4, err)) return false;
+    if (!ensure(st.keys, (size_t)n * 8, err) || !ensure(st.vals, (size_t)n * 4, err)) return false;
+    if (!ensure(st.keys_alt, (size_t)n * 8, err) || !ensure(st.vals_alt, (size_t)n * 4, err)) return false;
     if (!ensure(st.flag_a, (size_t)n * 4, err) || !ensure(st.flag_b, (size_t)n * 4, err)) return false;
     if (!ensure(st.rank_a, (size_t)n * 4, err) || !ensure(st.rank_b, (size_t)n * 4, err)) return false;
     if (!ensure(st.leaf_link, (size_t)n * 4, err) || !ensure(st.leaf_count, (size_t)n * 4, err)) return false;
@@ -406,9 +416,14 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
 
     // temp storage for rocPRIM (sized for the larger of sort and scan)
     size_t sort_bytes = 0, scan_bytes = 0;
-    rocprim::double_buffer<uint32_t> dkeys((uint32_t *)st.keys.ptr, (uint32_t *)st.keys_alt.ptr);
+    // bits per axis: one more than half of log2(n) (surfaces are 2-D sets), within 10..21
+    uint32_t bits = 1;
+    while ((1ull << (2 * (bits - 1))) < (uint64_t)n && bits < 21) bits++;
+    bits = bits < 10 ? 10 : bits;
+    const unsigned key_bits = 3 * bits;
+    rocprim::double_buffer<uint64_t> dkeys((uint64_t *)st.keys.ptr, (uint64_t *)st.keys_alt.ptr);
     rocprim::double_buffer<uint32_t> dvals((uint32_t *)st.vals.ptr, (uint32_t *)st.vals_alt.ptr);
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, dkeys, dvals, n, 0, 30, stream));
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, dkeys, dvals, n, 0, key_bits, stream));
     HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t *)st.flag_a.ptr, (uint32_t *)st.rank_a.ptr, 0u, n,
                                     rocprim::plus<uint32_t>(), stream));
     if (!ensure(st.temp, std::max(sort_bytes, scan_bytes), err)) return false;
@@ -416,12 +431,12 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, (uint32_t *)st.scene_bounds.ptr);
     hipLaunchKernelGGL(k_prim_bounds, dim3(blocks), dim3(256), 0, stream, in, n, (float4 *)st.plo.ptr, (float4 *)st.phi.ptr,
                        (uint32_t *)st.scene_bounds.ptr);
-    hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, (const float4 *)st.plo.ptr, (const float4 *)st.phi.ptr,
-                       (const uint32_t *)st.scene_bounds.ptr, (uint32_t *)st.keys.ptr, (uint32_t *)st.vals.ptr);
+    hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, bits, (const float4 *)st.plo.ptr, (const float4 *)st.phi.ptr,
+                       (const uint32_t *)st.scene_bounds.ptr, (uint64_t *)st.keys.ptr, (uint32_t *)st.vals.ptr);
     HIP_TRY(hipGetLastError());
     size_t tb = st.temp.bytes;
-    HIP_TRY(rocprim::radix_sort_pairs(st.temp.ptr, tb, dkeys, dvals, n, 0, 30, stream));
-    const uint32_t *keys = dkeys.current(), *vals = dvals.current();
+    HIP_TRY(rocprim::radix_sort_pairs(st.temp.ptr, tb, dkeys, dvals, n, 0, key_bits, stream));
+    const uint64_t *keys = dkeys.current(); const uint32_t *vals = dvals.current();
 
     // SAH refinement: the Karras hierarchy only clusters; bvh_sah.hip rebuilds the topology and reorders the primitives
     const bool sah = (flags & CRT_BVH_SAH_REFINE) != 0 && n >= 2;

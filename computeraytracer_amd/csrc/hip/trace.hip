@@ -364,8 +364,11 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
     }
 }
 
+#ifndef CRT_SHADE_WAVES
+#define CRT_SHADE_WAVES 6
+#endif
 template <int RNGM>
-__global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, Frame f, WfQueues q, uint32_t bounce, float4 *accum, uint32_t *hit_ids) {
+__global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene sc, Frame f, WfQueues q, uint32_t bounce, float4 *accum, uint32_t *hit_ids) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t in = bounce & 1, out = in ^ 1;
     // waves are dealt round-robin over the sub-queues; shading cost per path is near uniform, so no stealing
@@ -480,6 +483,8 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     const uint32_t resident = 256u * CRT_EXTEND_WAVES;
     nb = nb < resident ? ((nb + 15) / 16) * 16 : resident;
     const dim3 pgrid(nb);
+    static const uint32_t env_sgrid = [] { const char *e = getenv("CRT_WF_SHADE_GRID"); return (uint32_t)(e ? atoi(e) : 0); }();
+    const dim3 sgrid(env_sgrid ? env_sgrid : nb);
     const bool pcg = fs.rng_mode != CRT_RNG_REF;
     hipLaunchKernelGGL(k_wf_init, dim3(1), dim3(256), 0, stream, q, f.n_tiles, n_active, stats);
     if (pcg) hipLaunchKernelGGL((k_wf_generate<1>), gen_grid, block, 0, stream, f, q);
@@ -501,8 +506,8 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
             else hipLaunchKernelGGL((k_wf_extend<false, false, true>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
         }
         if (wf.time_kernels) { HIP_TRY(hipEventRecord(wf.ev[wf.ev_used + 1], stream)); wf.ev_used += 2; }
-        if (pcg) hipLaunchKernelGGL((k_wf_shade<1>), pgrid, block, 0, stream, sc, f, q, b, acc, hit_ids);
-        else hipLaunchKernelGGL((k_wf_shade<0>), pgrid, block, 0, stream, sc, f, q, b, acc, hit_ids);
+        if (pcg) hipLaunchKernelGGL((k_wf_shade<1>), sgrid, block, 0, stream, sc, f, q, b, acc, hit_ids);
+        else hipLaunchKernelGGL((k_wf_shade<0>), sgrid, block, 0, stream, sc, f, q, b, acc, hit_ids);
     }
     HIP_TRY(hipGetLastError());
     return true;

@@ -1,5 +1,5 @@
 run() { timeout -k 10 120 python bench.py --no-cpu-baseline --steps 16 --warmup 2 "$@" | python -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); c=d['config']; print(d['value'], 'Mrays/s  V', c['nodes_per_ray'], 'T', c['prim_tests_per_ray'], 'ext_ms', d['roofline']['launch_ms'], 'build', c['bvh_build_ms'])"; }
-for l in 8 16 24 32 40 48; do echo "== leaf_lanes=$l"; CRT_WF_LEAF_LANES=$l run || exit 1; done
-for r in 8 24 32; do echo "== refill=$r leaf=32"; CRT_WF_LEAF_LANES=32 CRT_WF_REFILL=$r run || exit 1; done
+d=json.loads(sys.stdin.readline()); c=d['config']; print(d['value'], 'Mrays/s  ms/step', d['ms_per_step'], 'ext_ms', d['roofline']['launch_ms'])"; }
+for g in 0 3072 6144 12288; do echo "== shade grid=$g"; CRT_WF_SHADE_GRID=$g run || exit 1; done
+for g in 2048 4096 8192; do echo "== s8 shade grid=$g"; CRT_LIB_PATH=$PWD/computeraytracer_amd/lib/libcrt_s8.so CRT_WF_SHADE_GRID=$g run || exit 1; done
