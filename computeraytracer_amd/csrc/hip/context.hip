@@ -111,13 +111,15 @@ int finish_timing(crt_context *ctx) {
     return CRT_OK;
 }
 
-int dispatch_one(crt_context *ctx, const crt_scene_params &p) {
+// n_batch > 1 (wavefront tracer only): p.camera.iteration is the first iteration of the batch, seeds[b] its b-th seed.
+int dispatch_one(crt_context *ctx, const crt_scene_params &p, uint32_t n_batch = 1, const float *seeds = nullptr) {
     std::string err;
     DeviceSceneHost sc = scene_view(ctx);
     FrameSetup fs = frame_setup(ctx);
     bool ok;
     if (ctx->cfg.tracer == CRT_TRACER_WAVEFRONT)
-        ok = launch_wavefront(ctx->stream, sc, fs, p, ctx->wf, (float *)ctx->accum.ptr, (uint32_t *)ctx->hit_ids.ptr,
+        ok = launch_wavefront(ctx->stream, sc, fs, p, n_batch, seeds, ctx->wf, (float *)ctx->accum.ptr,
+                              (uint32_t)((size_t)ctx->local_rows * ctx->cfg.width), (uint32_t *)ctx->hit_ids.ptr,
                               (DeviceStats *)ctx->stats.ptr, err);
     else
         ok = launch_megakernel(ctx->stream, sc, fs, p, (float *)ctx->accum.ptr, (uint32_t *)ctx->hit_ids.ptr,
@@ -305,10 +307,21 @@ int crt_render(crt_context *ctx, const crt_scene_params *params, uint32_t first_
     if ((rc = finish_timing(ctx))) return rc;
     CTX_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
     crt_scene_params p = *params;
-    for (uint32_t i = 0; i < n_iterations && rc == CRT_OK; i++) {
+    // The wavefront tracer traces several iterations of a small frame together (their paths share the queues, the
+    // accumulation still happens in iteration order, so the image is bit-identical): a launch needs a few million
+    // rays to fill 256 CUs, which one sample of a 1080p frame, or of one rank's bands of a 4K frame, does not supply.
+    uint32_t batch = 1;
+    if (ctx->cfg.tracer == CRT_TRACER_WAVEFRONT) {
+        static const double target = [] { const char *e = getenv("CRT_WF_BATCH_PATHS"); return e ? atof(e) : 12.0e6; }();
+        const double per_iter = (double)ctx->n_local_bands * 8.0 * ctx->grid_w;
+        batch = per_iter > 0.0 ? (uint32_t)(target / per_iter) : 1u;
+        batch = batch < 1u ? 1u : batch > 8u ? 8u : batch;
+    }
+    for (uint32_t i = 0; i < n_iterations && rc == CRT_OK; i += batch) {
+        const uint32_t nb = n_iterations - i < batch ? n_iterations - i : batch;
         p.camera.iteration = (float)(first_iteration + i);
         p.camera.seed = seeds[i];
-        rc = dispatch_one(ctx, p);
+        rc = dispatch_one(ctx, p, nb, seeds + i);
     }
     CTX_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->timing_pending = true;

@@ -23,7 +23,13 @@ struct Frame {
     uint32_t band_rank, band_world, n_local_bands, tiles_x, n_tiles;
     uint32_t max_bounces;
     uint64_t pcg_inc;
+    // wavefront batches: n_batch consecutive iterations traced together; iteration b of the batch has
+    // camera.iteration = iter0 + b and camera.seed = seeds[b]
+    uint32_t n_batch;
+    float iter0;
+    float seeds[8];
 };
+constexpr uint32_t kBatchMax = 8;
 
 static DeviceScene to_device_scene(const DeviceSceneHost &h) {
     DeviceScene d;
@@ -45,6 +51,8 @@ static Frame make_frame(const FrameSetup &fs, const crt_scene_params &params) {
     f.n_tiles = f.tiles_x * fs.n_local_bands;
     f.max_bounces = fs.max_bounces;
     f.pcg_inc = ((uint64_t)(uint32_t)params.camera.iteration << 1) | 1u;
+    f.n_batch = 1; f.iter0 = params.camera.iteration;
+    for (uint32_t b = 0; b < kBatchMax; b++) f.seeds[b] = params.camera.seed;
     return f;
 }
 
@@ -191,26 +199,28 @@ __global__ void k_wf_init(WfQueues q, uint32_t n_tiles, unsigned long long n_act
 template <int RNGM>
 __global__ __launch_bounds__(256) void k_wf_generate(Frame f, WfQueues q) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-    if (tile >= f.n_tiles) return;
+    const uint32_t vt = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;      // virtual tile: iteration-major over the batch
+    if (vt >= f.n_tiles * f.n_batch) return;
+    const uint32_t it = vt / f.n_tiles, tile = vt - it * f.n_tiles;
     uint32_t x = 0, y = 0, prow = 0;
     const bool active = tile_pixel(f, tile, lane, x, y, prow);
-    const uint32_t shard = tile / q.tiles_per_shard;
-    const uint32_t slot = shard * q.shard_cap + (tile - shard * q.tiles_per_shard) * 64 + lane;
+    const uint32_t shard = vt / q.tiles_per_shard;
+    const uint32_t slot = shard * q.shard_cap + (vt - shard * q.tiles_per_shard) * 64 + lane;
     if (!active) {
         q.ray_o[0][slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         q.ray_d[0][slot] = make_float4(0.0f, 0.0f, 1.0f, u2f(kDeadPixel));
         return;
     }
     const crt_camera_data &cam = f.p.camera;
+    const float seed = f.seeds[it], iteration = f.iter0 + (float)it;
     Rng<RNGM> rng;
-    rng.init(cam.seed, x, y, y * f.width + x, cam.iteration);
+    rng.init(seed, x, y, y * f.width + x, iteration);
     float ox, oy; hash_2(rng, ox, oy);
     float u = ((float)x + ox) / (float)f.width, v = ((float)y + oy) / (float)f.height;
     V3 o, d;
     camera_get_ray(cam, u, v, rng, o, d);
     const uint64_t rs = rng.pack();
-    q.ray_o[0][slot] = make_float4(o.x, o.y, o.z, 0.0f);
+    q.ray_o[0][slot] = make_float4(o.x, o.y, o.z, u2f(it));
     q.ray_d[0][slot] = make_float4(d.x, d.y, d.z, u2f(prow * f.width + x));
     q.thr[0][slot] = make_float4(1.0f, 1.0f, 1.0f, u2f((uint32_t)rs));
     q.emi[0][slot] = make_float4(0.0f, 0.0f, 0.0f, u2f((uint32_t)(rs >> 32)));
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
 #define CRT_SHADE_WAVES 6
 #endif
 template <int RNGM>
-__global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene sc, Frame f, WfQueues q, uint32_t bounce, float4 *accum, uint32_t *hit_ids) {
+__global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene sc, Frame f, WfQueues q, uint32_t bounce, float4 *pass_buf, uint32_t pass_stride, uint32_t *hit_ids) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t in = bounce & 1, out = in ^ 1;
     // waves are dealt round-robin over the sub-queues; shading cost per path is near uniform, so no stealing
@@ -382,7 +392,7 @@ __global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene s
         const uint32_t i = base + lane;
         bool alive = false;
         V3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), color = mk3(0, 0, 0), emitted = mk3(0, 0, 0);
-        uint32_t pix = kDeadPixel;
+        uint32_t pix = kDeadPixel, it = 0;
         Rng<RNGM> rng;
         if (i < n) {
             const uint32_t slot = s * q.shard_cap + i;
@@ -393,18 +403,17 @@ __global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene s
                 uint2 h = q.hit[slot];
                 o = mk3(o4.x, o4.y, o4.z); d = mk3(d4.x, d4.y, d4.z);
                 color = mk3(c4.x, c4.y, c4.z); emitted = mk3(e4.x, e4.y, e4.z);
-                rng.unpack((uint64_t)f2u(c4.w) | ((uint64_t)f2u(e4.w) << 32), f.pcg_inc);
+                it = f2u(o4.w);
+                rng.unpack((uint64_t)f2u(c4.w) | ((uint64_t)f2u(e4.w) << 32), ((uint64_t)(uint32_t)(f.iter0 + (float)it) << 1) | 1u);
                 const float t = u2f(h.x); const uint32_t id = h.y;
-                if (bounce == 0) hit_ids[pix] = id;
+                if (bounce == 0 && it + 1 == f.n_batch) hit_ids[pix] = id;
                 V3 pass = mk3(0.0f, 0.0f, 0.0f);
                 if (id == kIdMiss) pass = shade_miss(f.p, d, color);
                 else alive = shade_hit(sc, o, d, t, id, rng, color, emitted, pass);
                 if (alive && last) { alive = false; pass = mk3(0.0f, 0.0f, 0.0f); }     // "Kill ray after MAX_BOUNCES", compute.comp:457
-                if (!alive) {                                                            // main(), :470-476
+                if (!alive) {                                                            // main(), :470-473; k_wf_accumulate adds it in
                     pass = pass * (1.0f / 1.0f);
-                    float4 cum4 = accum[pix];
-                    V3 cum = accumulate(mk3(cum4.x, cum4.y, cum4.z), pass, f.p.camera.iteration);
-                    accum[pix] = make_float4(cum.x, cum.y, cum.z, f.p.camera.iteration);
+                    pass_buf[(size_t)it * pass_stride + pix] = make_float4(pass.x, pass.y, pass.z, 0.0f);
                 }
             }
         }
@@ -416,12 +425,32 @@ __global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene s
         if (alive) {
             const uint32_t slot = s * q.shard_cap + obase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             const uint64_t rs = rng.pack();
-            q.ray_o[out][slot] = make_float4(o.x, o.y, o.z, 0.0f);
+            q.ray_o[out][slot] = make_float4(o.x, o.y, o.z, u2f(it));
             q.ray_d[out][slot] = make_float4(d.x, d.y, d.z, u2f(pix));
             q.thr[out][slot] = make_float4(color.x, color.y, color.z, u2f((uint32_t)rs));
             q.emi[out][slot] = make_float4(emitted.x, emitted.y, emitted.z, u2f((uint32_t)(rs >> 32)));
         }
     }
+}
+
+// main()'s accumulation (compute.comp:470-476) for the iterations of a batch, in iteration order: every active pixel
+// owns exactly one path per iteration and k_wf_shade stored that path's radiance when it ended.
+__global__ __launch_bounds__(256) void k_wf_accumulate(Frame f, float4 *accum, const float4 *pass_buf, uint32_t pass_stride) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * 4 + wave;
+    if (tile >= f.n_tiles) return;
+    uint32_t x = 0, y = 0, prow = 0;
+    if (!tile_pixel(f, tile, lane, x, y, prow)) return;
+    const size_t pix = (size_t)prow * f.width + x;
+    const float4 cum4 = accum[pix];
+    V3 cum = mk3(cum4.x, cum4.y, cum4.z);
+    float iteration = f.iter0;
+    for (uint32_t b = 0; b < f.n_batch; b++) {
+        const float4 p = pass_buf[(size_t)b * pass_stride + pix];
+        iteration = f.iter0 + (float)b;
+        cum = accumulate(cum, mk3(p.x, p.y, p.z), iteration);
+    }
+    accum[pix] = make_float4(cum.x, cum.y, cum.z, iteration);
 }
 
 static bool ensure_dev(DeviceBuffer &b, size_t bytes, std::string &err) {
@@ -434,10 +463,15 @@ static bool ensure_dev(DeviceBuffer &b, size_t bytes, std::string &err) {
 }
 
 bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const FrameSetup &fs, const crt_scene_params &params,
-                      WavefrontState &wf, float *accum, uint32_t *hit_ids, DeviceStats *stats, std::string &err) {
+                      uint32_t n_batch, const float *seeds, WavefrontState &wf, float *accum, uint32_t accum_pixels,
+                      uint32_t *hit_ids, DeviceStats *stats, std::string &err) {
     DeviceScene sc = to_device_scene(sch);
     Frame f = make_frame(fs, params);
     if (f.n_tiles == 0) return true;
+    if (n_batch < 1 || n_batch > kBatchMax) { err = "wavefront batch must hold 1..8 iterations"; return false; }
+    f.n_batch = n_batch;
+    if (seeds) for (uint32_t b = 0; b < n_batch; b++) f.seeds[b] = seeds[b];
+    const uint32_t n_vt = f.n_tiles * n_batch;
     if (f.max_bounces > kMaxBounces) { err = "wavefront tracer supports at most 16 bounces"; return false; }
     if (sch.n_pairs + 1 >= kMaxLeafLink) { err = "wavefront tracer supports at most 2^26 primitives"; return false; }
     WfQueues q;
@@ -450,7 +484,7 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     q.refill = env_refill;
     static const uint32_t env_leaf = [] { const char *e = getenv("CRT_WF_LEAF_LANES"); int v = e ? atoi(e) : 16; return (uint32_t)(v < 1 ? 1 : v > 64 ? 64 : v); }();
     q.leaf_lanes = env_leaf;
-    q.tiles_per_shard = (f.n_tiles + q.n_shards - 1) / q.n_shards;
+    q.tiles_per_shard = (n_vt + q.n_shards - 1) / q.n_shards;
     q.shard_cap = q.tiles_per_shard * 64;
     const uint32_t cap = q.shard_cap * q.n_shards;
     if (wf.capacity < cap) {
@@ -461,6 +495,7 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
         if (!ensure_dev(wf.hit, (size_t)cap * 8, err) || !ensure_dev(wf.counters, (size_t)(2 * kMaxBounces + 1) * kShards * kCtrStride * 4, err)) return false;
         wf.capacity = cap;
     }
+    if (!ensure_dev(wf.pass, (size_t)n_batch * accum_pixels * 16, err)) return false;
     for (int k = 0; k < 2; k++) {
         q.ray_o[k] = (float4 *)wf.ray_o[k].ptr; q.ray_d[k] = (float4 *)wf.ray_d[k].ptr;
         q.thr[k] = (float4 *)wf.thr[k].ptr; q.emi[k] = (float4 *)wf.emi[k].ptr;
@@ -475,9 +510,10 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
         uint32_t rows = y0 < fs.grid_h ? (fs.grid_h - y0 < 8 ? fs.grid_h - y0 : 8) : 0;
         n_active += (unsigned long long)rows * fs.grid_w;
     }
-    const unsigned long long dead = (unsigned long long)f.n_tiles * 64 - n_active;
+    const unsigned long long dead = ((unsigned long long)f.n_tiles * 64 - n_active) * n_batch;
+    n_active *= n_batch;
     float4 *acc = (float4 *)accum;
-    const dim3 block(256), gen_grid((f.n_tiles + 3) / 4);
+    const dim3 block(256), gen_grid((n_vt + 3) / 4), acc_grid((f.n_tiles + 3) / 4);
     // persistent grids: 256 CUs x 6 resident blocks (LDS stack: 24 KiB per block); multiple of 8 blocks and of kShards waves
     uint32_t nb = (cap + 255) / 256;
     const uint32_t resident = 256u * CRT_EXTEND_WAVES;
@@ -486,7 +522,7 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     static const uint32_t env_sgrid = [] { const char *e = getenv("CRT_WF_SHADE_GRID"); return (uint32_t)(e ? atoi(e) : 0); }();
     const dim3 sgrid(env_sgrid ? env_sgrid : nb);
     const bool pcg = fs.rng_mode != CRT_RNG_REF;
-    hipLaunchKernelGGL(k_wf_init, dim3(1), dim3(256), 0, stream, q, f.n_tiles, n_active, stats);
+    hipLaunchKernelGGL(k_wf_init, dim3(1), dim3(256), 0, stream, q, n_vt, n_active, stats);
     if (pcg) hipLaunchKernelGGL((k_wf_generate<1>), gen_grid, block, 0, stream, f, q);
     else hipLaunchKernelGGL((k_wf_generate<0>), gen_grid, block, 0, stream, f, q);
     for (uint32_t b = 0; b < f.max_bounces; b++) {
@@ -506,9 +542,10 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
             else hipLaunchKernelGGL((k_wf_extend<false, false, true>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
         }
         if (wf.time_kernels) { HIP_TRY(hipEventRecord(wf.ev[wf.ev_used + 1], stream)); wf.ev_used += 2; }
-        if (pcg) hipLaunchKernelGGL((k_wf_shade<1>), sgrid, block, 0, stream, sc, f, q, b, acc, hit_ids);
-        else hipLaunchKernelGGL((k_wf_shade<0>), sgrid, block, 0, stream, sc, f, q, b, acc, hit_ids);
+        if (pcg) hipLaunchKernelGGL((k_wf_shade<1>), sgrid, block, 0, stream, sc, f, q, b, (float4 *)wf.pass.ptr, accum_pixels, hit_ids);
+        else hipLaunchKernelGGL((k_wf_shade<0>), sgrid, block, 0, stream, sc, f, q, b, (float4 *)wf.pass.ptr, accum_pixels, hit_ids);
     }
+    hipLaunchKernelGGL(k_wf_accumulate, acc_grid, block, 0, stream, f, acc, (const float4 *)wf.pass.ptr, accum_pixels);
     HIP_TRY(hipGetLastError());
     return true;
 }
