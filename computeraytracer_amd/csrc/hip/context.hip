@@ -312,10 +312,10 @@ int crt_render(crt_context *ctx, const crt_scene_params *params, uint32_t first_
     // rays to fill 256 CUs, which one sample of a 1080p frame, or of one rank's bands of a 4K frame, does not supply.
     uint32_t batch = 1;
     if (ctx->cfg.tracer == CRT_TRACER_WAVEFRONT) {
-        static const double target = [] { const char *e = getenv("CRT_WF_BATCH_PATHS"); return e ? atof(e) : 12.0e6; }();
+        static const double target = [] { const char *e = getenv("CRT_WF_BATCH_PATHS"); return e ? atof(e) : 134.0e6; }();
         const double per_iter = (double)ctx->n_local_bands * 8.0 * ctx->grid_w;
         batch = per_iter > 0.0 ? (uint32_t)(target / per_iter) : 1u;
-        batch = batch < 1u ? 1u : batch > 8u ? 8u : batch;
+        batch = batch < 1u ? 1u : batch > 16u ? 16u : batch;
     }
     for (uint32_t i = 0; i < n_iterations && rc == CRT_OK; i += batch) {
         const uint32_t nb = n_iterations - i < batch ? n_iterations - i : batch;

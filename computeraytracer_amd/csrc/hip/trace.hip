@@ -27,9 +27,9 @@ struct Frame {
     // camera.iteration = iter0 + b and camera.seed = seeds[b]
     uint32_t n_batch;
     float iter0;
-    float seeds[8];
+    float seeds[16];
 };
-constexpr uint32_t kBatchMax = 8;
+constexpr uint32_t kBatchMax = 16;
 
 static DeviceScene to_device_scene(const DeviceSceneHost &h) {
     DeviceScene d;
@@ -381,14 +381,23 @@ template <int RNGM>
 __global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene sc, Frame f, WfQueues q, uint32_t bounce, float4 *pass_buf, uint32_t pass_stride, uint32_t *hit_ids) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t in = bounce & 1, out = in ^ 1;
-    // waves are dealt round-robin over the sub-queues; shading cost per path is near uniform, so no stealing
+    // The 64-path batches of ALL sub-queues, concatenated, are cut into one contiguous run per wave (sub-queues shrink
+    // unevenly: sky tiles die at the first bounce; shading cost per path is near uniform, so no stealing).  Waves that
+    // run together thus sit in different sub-queues in proportion to their sizes and spread the compaction atomics
+    // over the counters.  Lane s holds sub-queue s's size; an inclusive wave scan of the batch counts locates the
+    // sub-queue of a global batch index with one ballot.
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t s = wave_id % q.n_shards, wave_in_shard = wave_id / q.n_shards, waves_per_shard = n_waves / q.n_shards;
-    if (wave_in_shard >= waves_per_shard) return;
-    const uint32_t n = q.counts[(bounce * kShards + s) * kCtrStride];
-    uint32_t *out_count = q.counts + ((bounce + 1) * kShards + s) * kCtrStride;
+    const uint32_t my_n = lane < q.n_shards ? q.counts[(bounce * kShards + lane) * kCtrStride] : 0u;      // n_shards <= 64
+    uint32_t incl = (my_n + 63u) / 64u;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, off); if ((int)lane >= off) incl += v; }
+    const uint32_t n_batches = (uint32_t)__shfl((int)incl, 63);
     const bool last = bounce + 1 >= f.max_bounces;
-    for (uint32_t base = wave_in_shard * 64; base < n; base += waves_per_shard * 64) {
+    const uint32_t g_begin = (uint32_t)((uint64_t)wave_id * n_batches / n_waves), g_end = (uint32_t)((uint64_t)(wave_id + 1) * n_batches / n_waves);
+    for (uint32_t g = g_begin; g < g_end; g++) {
+        const uint32_t s = (uint32_t)__builtin_ctzll(__ballot(incl > g));
+        const uint32_t n = (uint32_t)__shfl((int)my_n, (int)s);
+        const uint32_t base = (g - ((uint32_t)__shfl((int)incl, (int)s) - (n + 63u) / 64u)) * 64u;
+        uint32_t *out_count = q.counts + ((bounce + 1) * kShards + s) * kCtrStride;
         const uint32_t i = base + lane;
         bool alive = false;
         V3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), color = mk3(0, 0, 0), emitted = mk3(0, 0, 0);
@@ -468,7 +477,7 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     DeviceScene sc = to_device_scene(sch);
     Frame f = make_frame(fs, params);
     if (f.n_tiles == 0) return true;
-    if (n_batch < 1 || n_batch > kBatchMax) { err = "wavefront batch must hold 1..8 iterations"; return false; }
+    if (n_batch < 1 || n_batch > kBatchMax) { err = "wavefront batch must hold 1..16 iterations"; return false; }
     f.n_batch = n_batch;
     if (seeds) for (uint32_t b = 0; b < n_batch; b++) f.seeds[b] = seeds[b];
     const uint32_t n_vt = f.n_tiles * n_batch;
@@ -476,7 +485,7 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     if (sch.n_pairs + 1 >= kMaxLeafLink) { err = "wavefront tracer supports at most 2^26 primitives"; return false; }
     WfQueues q;
     static const uint32_t env_shards = [] { const char *e = getenv("CRT_WF_SHARDS"); int v = e ? atoi(e) : 64;
-                                            return (uint32_t)((v >= 1 && v <= (int)kShards && (v & (v - 1)) == 0) ? v : 64); }();
+                                            return (uint32_t)((v >= 1 && v <= 64 && (v & (v - 1)) == 0) ? v : 64); }();     // k_wf_shade: one lane per sub-queue
     q.n_shards = env_shards;
     static const uint32_t env_precheck = [] { const char *e = getenv("CRT_WF_PRECHECK"); return (uint32_t)(e ? atoi(e) : 1); }();
     q.precheck = env_precheck;
