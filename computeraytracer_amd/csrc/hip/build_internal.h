@@ -84,7 +84,7 @@ struct WavefrontState {
 
 bool launch_megakernel(hipStream_t stream, const DeviceSceneHost &sc, const FrameSetup &fs, const crt_scene_params &params,
                        float *accum, uint32_t *hit_ids, DeviceStats *stats, std::string &err);
-// n_batch (1..16) consecutive iterations traced together: iteration b has camera.iteration = params.camera.iteration + b
+// n_batch (1..64) consecutive iterations traced together: iteration b has camera.iteration = params.camera.iteration + b
 // and camera.seed = seeds[b] (seeds == nullptr: params.camera.seed); accum_pixels = pixels of the packed band buffer.
 bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sc, const FrameSetup &fs, const crt_scene_params &params,
                       uint32_t n_batch, const float *seeds, WavefrontState &wf, float *accum, uint32_t accum_pixels,

@@ -315,7 +315,7 @@ int crt_render(crt_context *ctx, const crt_scene_params *params, uint32_t first_
         static const double target = [] { const char *e = getenv("CRT_WF_BATCH_PATHS"); return e ? atof(e) : 134.0e6; }();
         const double per_iter = (double)ctx->n_local_bands * 8.0 * ctx->grid_w;
         batch = per_iter > 0.0 ? (uint32_t)(target / per_iter) : 1u;
-        batch = batch < 1u ? 1u : batch > 16u ? 16u : batch;
+        batch = batch < 1u ? 1u : batch > 64u ? 64u : batch;
     }
     for (uint32_t i = 0; i < n_iterations && rc == CRT_OK; i += batch) {
         const uint32_t nb = n_iterations - i < batch ? n_iterations - i : batch;

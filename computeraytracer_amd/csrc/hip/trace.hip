@@ -27,9 +27,9 @@ struct Frame {
     // camera.iteration = iter0 + b and camera.seed = seeds[b]
     uint32_t n_batch;
     float iter0;
-    float seeds[16];
+    float seeds[64];
 };
-constexpr uint32_t kBatchMax = 16;
+constexpr uint32_t kBatchMax = 64;
 
 static DeviceScene to_device_scene(const DeviceSceneHost &h) {
     DeviceScene d;
@@ -477,7 +477,7 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     DeviceScene sc = to_device_scene(sch);
     Frame f = make_frame(fs, params);
     if (f.n_tiles == 0) return true;
-    if (n_batch < 1 || n_batch > kBatchMax) { err = "wavefront batch must hold 1..16 iterations"; return false; }
+    if (n_batch < 1 || n_batch > kBatchMax) { err = "wavefront batch must hold 1..64 iterations"; return false; }
     f.n_batch = n_batch;
     if (seeds) for (uint32_t b = 0; b < n_batch; b++) f.seeds[b] = seeds[b];
     const uint32_t n_vt = f.n_tiles * n_batch;
