@@ -79,7 +79,11 @@ int crt_dispatch(crt_context *ctx, const crt_scene_params *params);
 
 /* n dispatches enqueued back to back: dispatch i uses *params with
  * camera.iteration = first_iteration + i and camera.seed = seeds[i].
- * Equivalent to n crt_dispatch calls (bit-identical image). */
+ * Equivalent to n crt_dispatch calls (bit-identical image).  The wavefront
+ * tracer traces up to 64 consecutive iterations as one batch (as many as keep
+ * a batch within ~134 M paths; CRT_WF_BATCH_PATHS overrides) and adds their
+ * radiance to the image in iteration order; device memory for the queues
+ * grows with the batch (136 bytes per path). */
 int crt_render(crt_context *ctx, const crt_scene_params *params, uint32_t first_iteration,
                uint32_t n_iterations, const float *seeds);
 
@@ -92,8 +96,9 @@ int crt_sync(crt_context *ctx);
 int crt_image_read(crt_context *ctx, float *rgba, size_t n_floats);
 
 /* Build-only diagnostic: primary-hit primitive ID per pixel of the most
- * recent dispatch (CRT_ID_MISS where the camera ray hit nothing or the pixel
- * is outside the rendered grid). */
+ * recent dispatch, i.e. of the last iteration of the last crt_render
+ * (CRT_ID_MISS where the camera ray hit nothing or the pixel is outside the
+ * rendered grid). */
 int crt_hit_ids_read(crt_context *ctx, uint32_t *ids, size_t n_ids);
 
 /* Device pointer + size of this context's packed band buffer (the rows it
