@@ -18,6 +18,7 @@ KIND_SPHERE, KIND_QUAD, KIND_TRI = 0, 1, 2
 RNG_REF, RNG_PCG = 0, 1
 TRACER_MEGAKERNEL, TRACER_WAVEFRONT = 0, 1
 FLAG_FULL_IMAGE = 1
+FLAG_DEBUG_SMALL_STACK = 2
 BVH_LBVH, BVH_SAH_REFINE, BVH_LEAF_COLLAPSE, BVH_WIDE = 0, 1, 2, 4
 
 # numpy views of the POD layouts in include/crt/types.h

@@ -65,6 +65,7 @@ struct FrameSetup {
     uint32_t max_bounces;
     uint32_t rng_mode;
     uint32_t instrumented;
+    uint32_t small_stack;            // CRT_FLAG_DEBUG_SMALL_STACK
 };
 
 struct DeviceStats {

@@ -91,6 +91,7 @@ FrameSetup frame_setup(const crt_context *ctx) {
     fs.max_bounces = ctx->cfg.max_bounces ? ctx->cfg.max_bounces : 10;   // MAX_BOUNCES, compute.comp:16
     fs.rng_mode = ctx->cfg.rng_mode;
     fs.instrumented = (uint32_t)ctx->instrumented;
+    fs.small_stack = (ctx->cfg.flags & CRT_FLAG_DEBUG_SMALL_STACK) ? 1u : 0u;
     return fs;
 }
 

@@ -35,7 +35,7 @@ struct DeviceScene {
 #define CRT_LDS_STACK 24
 #endif
 constexpr int kLdsStack = CRT_LDS_STACK;     // per-lane LDS stack entries; deeper levels spill to scratch
-constexpr int kSpillStack = 80 - CRT_LDS_STACK;
+constexpr int kSpillStack = 96;               // pair trees are at most 95 deep (63 Morton bits + 32 index bits); lds_depth may be as low as 1
 constexpr uint32_t kIdMiss = 0xFFFFFFFFu;
 
 CRT_DEV bool accept_hit(float t, uint32_t id, float best_t, uint32_t best_id) {
@@ -209,16 +209,16 @@ CRT_DEV uint32_t make_entry(uint32_t link, uint32_t count_kind) {
 }
 
 // Pops the next entry; false when the traversal is finished (best_t / best_id are final).
-CRT_DEV bool trav_pop(Traversal &tr, const uint32_t *stack, uint32_t stack_stride, const uint32_t *spill) {
+CRT_DEV bool trav_pop(Traversal &tr, const uint32_t *stack, uint32_t stack_stride, const uint32_t *spill, int lds_depth) {
     if (tr.sp == 0) return false;
     tr.sp--;
-    tr.cur = tr.sp < kLdsStack ? stack[tr.sp * stack_stride] : spill[tr.sp - kLdsStack];
+    tr.cur = tr.sp < lds_depth ? stack[tr.sp * stack_stride] : spill[tr.sp - lds_depth];
     return true;
 }
 
 // Inner phase: one pair visit (64-byte fetch, two slab tests, ordered descent).  tr.cur must be an inner entry.
 template <bool COUNT>
-CRT_DEV bool trav_inner(const DeviceScene &sc, Traversal &tr, uint32_t *stack, uint32_t stack_stride, uint32_t *spill, Counts &cnt) {
+CRT_DEV bool trav_inner(const DeviceScene &sc, Traversal &tr, uint32_t *stack, uint32_t stack_stride, uint32_t *spill, int lds_depth, Counts &cnt) {
     const float4 *p = sc.nodes + 4 * (size_t)tr.cur;
     float4 lo0 = p[0], hi0 = p[1], lo1 = p[2], hi1 = p[3];
     if (COUNT) cnt.nodes += 2;
@@ -230,24 +230,24 @@ CRT_DEV bool trav_inner(const DeviceScene &sc, Traversal &tr, uint32_t *stack, u
     if (h0 && h1) {
         bool first0 = tn0 <= tn1;
         uint32_t nearc = first0 ? e0 : e1, farc = first0 ? e1 : e0;
-        if (tr.sp < kLdsStack) stack[tr.sp * stack_stride] = farc; else if (tr.sp < kLdsStack + kSpillStack) spill[tr.sp - kLdsStack] = farc;
+        if (tr.sp < lds_depth) stack[tr.sp * stack_stride] = farc; else if (tr.sp < lds_depth + kSpillStack) spill[tr.sp - lds_depth] = farc;
         tr.sp++;
         tr.cur = nearc;
         return true;
     }
     if (h0) { tr.cur = e0; return true; }
     if (h1) { tr.cur = e1; return true; }
-    return trav_pop(tr, stack, stack_stride, spill);
+    return trav_pop(tr, stack, stack_stride, spill, lds_depth);
 }
 
 // Leaf phase: test the primitives of the leaf entry in tr.cur, then pop.
 template <bool COUNT>
-CRT_DEV bool trav_leaf(const DeviceScene &sc, Traversal &tr, const uint32_t *stack, uint32_t stack_stride, const uint32_t *spill, Counts &cnt) {
+CRT_DEV bool trav_leaf(const DeviceScene &sc, Traversal &tr, const uint32_t *stack, uint32_t stack_stride, const uint32_t *spill, int lds_depth, Counts &cnt) {
     const uint32_t e = tr.cur;
     const uint32_t kind = (e >> 29) & 3u, n = ((e >> 26) & 7u) + 1u, first = e & (kMaxLeafLink - 1u);
     test_leaf<COUNT>(sc, tr.o, tr.d, first, (kind << 28) | n, tr.best_t, tr.best_id, cnt);
     tr.tfar = tr.best_t * 1.000004f;       // relative pad (2^-18) on the far bound
-    return trav_pop(tr, stack, stack_stride, spill);
+    return trav_pop(tr, stack, stack_stride, spill, lds_depth);
 }
 
 // The shader's HitRecord (compute.comp:195-203), rebuilt for the winning primitive from the

@@ -22,7 +22,7 @@ namespace crt {
 #define CRT_WIDE_LDS_STACK 12
 #endif
 constexpr int kWideLds = CRT_WIDE_LDS_STACK;          // 8-byte entries per lane in LDS; deeper levels spill to scratch
-constexpr int kWideSpill = 64 - CRT_WIDE_LDS_STACK;   // the build refuses trees deeper than 64 levels
+constexpr int kWideSpill = 64;                        // the build refuses trees deeper than 64 levels (lds_depth may be as low as 1)
 constexpr uint32_t kWideNodeF4 = 8;                   // = kWideStrideF4 (build_internal.h)
 constexpr uint32_t kEmptyLeaf = kLeafTag | (3u << 29);
 
@@ -50,13 +50,13 @@ CRT_DEV void wide_begin(WideTrav &tr, V3 o, V3 d) {
 // Next child in visiting order; false when nothing is left (best_t / best_id are final).
 // SPILL = false: the tree has at most kWideLds + 1 levels, so the LDS stack cannot overflow and no scratch is touched.
 template <bool SPILL>
-CRT_DEV bool wide_advance(const float4 *nodes, WideTrav &tr, const uint2 *stack, uint32_t stack_stride, const uint2 *spill) {
+CRT_DEV bool wide_advance(const float4 *nodes, WideTrav &tr, const uint2 *stack, uint32_t stack_stride, const uint2 *spill, int lds_depth) {
     if ((tr.g_pend & 0xFFu) == 0u) {
         if (tr.sp == 0) return false;
         tr.sp--;
         uint2 e;
-        if (!SPILL || tr.sp < kWideLds) e = stack[tr.sp * stack_stride];
-        else e = spill[tr.sp - kWideLds];
+        if (!SPILL || tr.sp < lds_depth) e = stack[tr.sp * stack_stride];
+        else e = spill[tr.sp - lds_depth];
         tr.g_hdr = e.x; tr.g_pend = e.y;
     }
     const uint32_t pos = (uint32_t)__builtin_ctz(tr.g_pend);        // the mask is non-zero, so this is one of its 8 bits
@@ -75,7 +75,7 @@ CRT_DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma
 
 // Node visit without the final wide_advance: tests the eight children of node tr.cur and makes them the top group.
 template <bool COUNT, bool SPILL>
-CRT_DEV void wide_visit(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_t stack_stride, uint2 *spill, Counts &cnt) {
+CRT_DEV void wide_visit(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_t stack_stride, uint2 *spill, int lds_depth, Counts &cnt) {
     const uint32_t node = tr.cur;
     const float4 *p = nodes + (size_t)kWideNodeF4 * node;
     const float4 h = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
@@ -126,8 +126,8 @@ CRT_DEV void wide_visit(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_
         if (tr.oct & 4u) pm = ((pm & 0x0Fu) << 4) | (pm >> 4);
         if ((tr.g_pend & 0xFFu) != 0u) {
             const uint2 e = make_uint2(tr.g_hdr, tr.g_pend);
-            if (!SPILL || tr.sp < kWideLds) stack[tr.sp * stack_stride] = e;
-            else if (tr.sp < kWideLds + kWideSpill) spill[tr.sp - kWideLds] = e;
+            if (!SPILL || tr.sp < lds_depth) stack[tr.sp * stack_stride] = e;
+            else if (tr.sp < lds_depth + kWideSpill) spill[tr.sp - lds_depth] = e;
             tr.sp++;
         }
         tr.g_hdr = f2u(h.w);
@@ -137,21 +137,21 @@ CRT_DEV void wide_visit(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_
 
 // Inner step: tr.cur is a node index.
 template <bool COUNT, bool SPILL>
-CRT_DEV bool wide_inner(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_t stack_stride, uint2 *spill, Counts &cnt) {
-    wide_visit<COUNT, SPILL>(nodes, tr, stack, stack_stride, spill, cnt);
-    return wide_advance<SPILL>(nodes, tr, stack, stack_stride, spill);
+CRT_DEV bool wide_inner(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_t stack_stride, uint2 *spill, int lds_depth, Counts &cnt) {
+    wide_visit<COUNT, SPILL>(nodes, tr, stack, stack_stride, spill, lds_depth, cnt);
+    return wide_advance<SPILL>(nodes, tr, stack, stack_stride, spill, lds_depth);
 }
 
 // Leaf step: tr.cur is a tagged leaf entry.
 template <bool COUNT, bool SPILL>
-CRT_DEV bool wide_leaf(const DeviceScene &sc, WideTrav &tr, const uint2 *stack, uint32_t stack_stride, const uint2 *spill, Counts &cnt) {
+CRT_DEV bool wide_leaf(const DeviceScene &sc, WideTrav &tr, const uint2 *stack, uint32_t stack_stride, const uint2 *spill, int lds_depth, Counts &cnt) {
     const uint32_t e = tr.cur;
     const uint32_t kind = (e >> 29) & 3u, n = ((e >> 26) & 7u) + 1u, first = e & (kMaxLeafLink - 1u);
     if (kind != 3u) {                                   // 3 = empty slot (a box test can only reach it through rounding)
         test_leaf<COUNT>(sc, tr.o, tr.d, first, (kind << 28) | n, tr.best_t, tr.best_id, cnt);
         tr.tfar = tr.best_t * 1.000004f;                // relative pad (2^-18) on the far bound
     }
-    return wide_advance<SPILL>(sc.wide, tr, stack, stack_stride, spill);
+    return wide_advance<SPILL>(sc.wide, tr, stack, stack_stride, spill, lds_depth);
 }
 
 }  // namespace crt

@@ -179,6 +179,7 @@ struct WfQueues {
     uint32_t precheck;                     // experiment knob: load the cursor before the fetch atomic
     uint32_t refill;                       // idle lanes that trigger a refill
     uint32_t leaf_lanes;                   // lanes waiting at a leaf that trigger a leaf-test phase
+    uint32_t lds_depth;                    // LDS stack entries per lane (lower only with CRT_FLAG_DEBUG_SMALL_STACK)
 };
 
 constexpr uint32_t kDeadPixel = 0xFFFFFFFFu;   // queue entry of a lane outside the rendered grid (ragged sizes only)
@@ -250,8 +251,8 @@ template <bool SPILL> struct LaneTrav<false, SPILL> {          // sibling-pair B
     Traversal tr;
     CRT_DEV void begin(V3 o, V3 d) { trav_begin(tr, o, d); }
     CRT_DEV bool at_leaf() const { return (tr.cur & kLeafTag) != 0; }
-    template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, Entry *stack, Entry *spill, Counts &c) { return trav_inner<COUNT>(sc, tr, stack, 256, spill, c); }
-    template <bool COUNT> CRT_DEV bool leaf(const DeviceScene &sc, Entry *stack, Entry *spill, Counts &c) { return trav_leaf<COUNT>(sc, tr, stack, 256, spill, c); }
+    template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, Entry *stack, Entry *spill, int depth, Counts &c) { return trav_inner<COUNT>(sc, tr, stack, 256, spill, depth, c); }
+    template <bool COUNT> CRT_DEV bool leaf(const DeviceScene &sc, Entry *stack, Entry *spill, int depth, Counts &c) { return trav_leaf<COUNT>(sc, tr, stack, 256, spill, depth, c); }
 };
 template <bool SPILL> struct LaneTrav<true, SPILL> {           // 8-wide quantised BVH (intersect_wide.h)
     using Entry = uint2;
@@ -259,8 +260,8 @@ template <bool SPILL> struct LaneTrav<true, SPILL> {           // 8-wide quantis
     WideTrav tr;
     CRT_DEV void begin(V3 o, V3 d) { wide_begin(tr, o, d); }
     CRT_DEV bool at_leaf() const { return (tr.cur & kLeafTag) != 0; }
-    template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, Entry *stack, Entry *spill, Counts &c) { return wide_inner<COUNT, SPILL>(sc.wide, tr, stack, 256, spill, c); }
-    template <bool COUNT> CRT_DEV bool leaf(const DeviceScene &sc, Entry *stack, Entry *spill, Counts &c) { return wide_leaf<COUNT, SPILL>(sc, tr, stack, 256, spill, c); }
+    template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_inner<COUNT, SPILL>(sc.wide, tr, stack, 256, spill, depth, c); }
+    template <bool COUNT> CRT_DEV bool leaf(const DeviceScene &sc, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_leaf<COUNT, SPILL>(sc, tr, stack, 256, spill, depth, c); }
 };
 static_assert(kLdsStack * 4 == kWideLds * 8, "both stack layouts use the same LDS block");
 
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
     LT lt;
     typename LT::Entry spill[LT::kSpill];
     typename LT::Entry *stack = (typename LT::Entry *)s_stack + threadIdx.x;
+    const int lds_depth = (int)q.lds_depth;      // LDS stack entries per lane in use (the block holds 12 x 8 bytes = 24 x 4 bytes per lane)
     for (;;) {
         const unsigned long long idle = __ballot(!busy);
         if (COUNT) c_iter++;
@@ -352,10 +354,10 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
         bool more = true;
         if (n_leaf >= q.leaf_lanes || !any_inner) {
             if (COUNT) { c_leaf++; c_leaf_lanes += n_leaf; }
-            if (at_leaf) more = lt.template leaf<COUNT>(sc, stack, spill, cnt);
+            if (at_leaf) more = lt.template leaf<COUNT>(sc, stack, spill, lds_depth, cnt);
         } else {
             if (COUNT) { c_inner++; c_inner_lanes += (uint32_t)__popcll(__ballot(busy && !at_leaf)); }
-            if (busy && !at_leaf) more = lt.template inner<COUNT>(sc, stack, spill, cnt);
+            if (busy && !at_leaf) more = lt.template inner<COUNT>(sc, stack, spill, lds_depth, cnt);
         }
         if (!more) {
             q.hit[slot] = make_uint2(f2u(lt.tr.best_t), lt.tr.best_id);
@@ -540,7 +542,8 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
             if (wf.ev_used + 2 > wf.ev.size()) { hipEvent_t a, c; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&c)); wf.ev.push_back(a); wf.ev.push_back(c); }
             HIP_TRY(hipEventRecord(wf.ev[wf.ev_used], stream));
         }
-        if (sc.wide && sch.wide_levels <= (uint32_t)kWideLds + 1u) {      // at most levels - 1 groups wait on the stack
+        q.lds_depth = fs.small_stack ? 1u : (sc.wide ? (uint32_t)kWideLds : (uint32_t)kLdsStack);
+        if (sc.wide && sch.wide_levels <= q.lds_depth + 1u) {      // at most levels - 1 groups wait on the stack
             if (fs.instrumented) hipLaunchKernelGGL((k_wf_extend<true, true, false>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
             else hipLaunchKernelGGL((k_wf_extend<false, true, false>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
         } else if (sc.wide) {

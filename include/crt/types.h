@@ -138,8 +138,11 @@ enum {
 
 /* crt_config.flags */
 enum {
-    CRT_FLAG_FULL_IMAGE = 1u << 0  /* render all W x H pixels; default renders floor(W/8)*8 x floor(H/8)*8
+    CRT_FLAG_FULL_IMAGE = 1u << 0, /* render all W x H pixels; default renders floor(W/8)*8 x floor(H/8)*8
                                       like dispatch(W/8, H/8, 1), vk_engine.cpp:1435 */
+    CRT_FLAG_DEBUG_SMALL_STACK = 1u << 1 /* test hook: the wavefront tracer keeps one traversal-stack entry per lane in LDS,
+                                      so the scratch-memory overflow path (otherwise only reached by trees deeper than the
+                                      LDS stack) runs on every scene */
 };
 
 typedef struct crt_config {

@@ -358,3 +358,14 @@ def test_full_size_tree_formats_agree(ctx):
     c_img, c_ids, _ = _gpu_render(ctx, scene, w, h, 2, bvh=abi.BVH_LBVH | abi.BVH_WIDE, tracer=abi.TRACER_WAVEFRONT)
     assert np.array_equal(a_ids, c_ids) and np.array_equal(a_img.view(np.uint32), c_img.view(np.uint32))
     assert (a_img[..., 3] == 2).all() and (a_ids != abi.ID_MISS).any()
+
+
+@pytest.mark.parametrize("bvh", [abi.BVH_LBVH, abi.BVH_SAH_REFINE | abi.BVH_WIDE], ids=["pairs", "wide"])
+def test_stack_overflow_path(ctx, golden_dir, bvh):
+    # CRT_FLAG_DEBUG_SMALL_STACK leaves one LDS stack entry per lane, so every deeper push goes through the
+    # scratch-memory overflow path that real scenes only reach with very deep trees; the image must not change
+    w, h = 96, 60
+    scene = abi.builtin_scene("cirno", w, h, golden_dir)
+    img, ids, ps = _gpu_render(ctx, scene, w, h, 2, bvh=bvh, tracer=abi.TRACER_WAVEFRONT, flags=abi.FLAG_DEBUG_SMALL_STACK)
+    ref_img, ref_ids, _ = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_FAST)
+    assert np.array_equal(ids, ref_ids) and np.array_equal(img.view(np.uint32), ref_img.view(np.uint32))
