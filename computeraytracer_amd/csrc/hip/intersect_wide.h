@@ -1,9 +1,9 @@
 // intersect_wide.h -- closest-hit search over the 8-wide quantised BVH (node format: bvh_wide.hip).
 //
 // One step = four 16-byte loads (header + 48 quantised plane bytes), eight slab tests, one 8-bit hit mask.
-// The hit children of a node wait as ONE stack entry {child_base | imask, node | pending mask}; the pending mask
-// is stored in visiting order (bit position = slot ^ ray octant), so "next child" is the lowest set bit.  The top
-// entry lives in registers.  Inner children are addressed as child_base + popcount(imask below slot); the link of a
+// The hit children of a node wait as ONE stack entry {child_base | imask, node | pending mask}.  The visiting order of
+// a group is slot ^ ray octant ascending; "next child" of a pending mask is one byte read from a 2 KiB LDS table
+// indexed by (octant, mask) (wide_order_table), cheaper than permuting the mask.  The top entry lives in registers.  Inner children are addressed as child_base + popcount(imask below slot); the link of a
 // leaf slot is loaded only when that slot is actually taken.
 //
 // Conservativeness.  The planes of a child box are the real numbers P = origin + q * 2^e.  A step evaluates
@@ -31,8 +31,8 @@ struct WideTrav {
     float best_t, tfar;
     uint32_t best_id;
     uint32_t cur;              // inner: node index; leaf: tagged entry (kLeafTag | kind | count | first)
-    uint32_t g_hdr, g_pend;    // top group: child_base << 8 | imask ; node << 8 | pending mask in visiting order
-    uint32_t oct;              // bit a set: direction component a is negative
+    uint32_t g_hdr, g_pend;    // top group: child_base << 8 | imask ; node << 8 | pending mask (bit = slot)
+    uint32_t oct8;             // ray octant << 8 (octant bit a set: direction component a is negative)
     int sp;
 };
 
@@ -42,15 +42,27 @@ CRT_DEV void wide_begin(WideTrav &tr, V3 o, V3 d) {
     tr.idir.y = __builtin_fabsf(d.y) > 1e-30f ? 1.0f / d.y : __builtin_copysignf(1e30f, d.y);
     tr.idir.z = __builtin_fabsf(d.z) > 1e-30f ? 1.0f / d.z : __builtin_copysignf(1e30f, d.z);
     tr.noid = mk3(-(o.x * tr.idir.x), -(o.y * tr.idir.y), -(o.z * tr.idir.z));
-    tr.oct = (f2u(tr.idir.x) >> 31) | ((f2u(tr.idir.y) >> 31) << 1) | ((f2u(tr.idir.z) >> 31) << 2);
+    tr.oct8 = ((f2u(tr.idir.x) >> 31) | ((f2u(tr.idir.y) >> 31) << 1) | ((f2u(tr.idir.z) >> 31) << 2)) << 8;
     tr.best_t = kInf; tr.tfar = kInf; tr.best_id = kIdMiss;
     tr.cur = 0; tr.g_hdr = 0; tr.g_pend = 0; tr.sp = 0;
 }
 
 // Next child in visiting order; false when nothing is left (best_t / best_id are final).
 // SPILL = false: the tree has at most kWideLds + 1 levels, so the LDS stack cannot overflow and no scratch is touched.
+// order[(octant << 8) | mask] = the slot s of `mask` with the smallest s ^ octant (filled by wide_order_table).
+constexpr uint32_t kWideOrderBytes = 8 * 256;
+CRT_DEV void wide_order_table(uint8_t *order, uint32_t tid, uint32_t n_threads) {
+    for (uint32_t e = tid; e < kWideOrderBytes; e += n_threads) {
+        const uint32_t oct = e >> 8, mask = e & 0xFFu;
+        uint32_t best = 0, best_pos = 8;
+        for (uint32_t sl = 0; sl < 8; sl++)
+            if (((mask >> sl) & 1u) && (sl ^ oct) < best_pos) { best_pos = sl ^ oct; best = sl; }
+        order[e] = (uint8_t)best;
+    }
+}
+
 template <bool SPILL>
-CRT_DEV bool wide_advance(const float4 *nodes, WideTrav &tr, const uint2 *stack, uint32_t stack_stride, const uint2 *spill, int lds_depth) {
+CRT_DEV bool wide_advance(const float4 *nodes, const uint8_t *order, WideTrav &tr, const uint2 *stack, uint32_t stack_stride, const uint2 *spill, int lds_depth) {
     if ((tr.g_pend & 0xFFu) == 0u) {
         if (tr.sp == 0) return false;
         tr.sp--;
@@ -59,10 +71,10 @@ CRT_DEV bool wide_advance(const float4 *nodes, WideTrav &tr, const uint2 *stack,
         else e = spill[tr.sp - lds_depth];
         tr.g_hdr = e.x; tr.g_pend = e.y;
     }
-    const uint32_t pos = (uint32_t)__builtin_ctz(tr.g_pend);        // the mask is non-zero, so this is one of its 8 bits
-    tr.g_pend &= tr.g_pend - 1u;
-    const uint32_t slot = pos ^ tr.oct, imask = tr.g_hdr & 0xFFu;
-    if ((imask >> slot) & 1u) tr.cur = (tr.g_hdr >> 8) + (uint32_t)__builtin_popcount(imask & ((1u << slot) - 1u));
+    const uint32_t slot = order[tr.oct8 | (tr.g_pend & 0xFFu)];     // the mask is non-zero
+    const uint32_t bit = 1u << slot, imask = tr.g_hdr & 0xFFu;
+    tr.g_pend ^= bit;
+    if (imask & bit) tr.cur = (tr.g_hdr >> 8) + (uint32_t)__builtin_popcount(imask & (bit - 1u));
     else tr.cur = ((const uint32_t *)nodes)[(size_t)(tr.g_pend >> 8) * (kWideNodeF4 * 4u) + 16u + slot];
     return true;
 }
@@ -119,11 +131,6 @@ CRT_DEV void wide_visit(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_
         }
     }
     if (m != 0u) {
-        // visiting order: bit position = slot ^ octant
-        uint32_t pm = m;
-        if (tr.oct & 1u) pm = ((pm & 0x55u) << 1) | ((pm >> 1) & 0x55u);
-        if (tr.oct & 2u) pm = ((pm & 0x33u) << 2) | ((pm >> 2) & 0x33u);
-        if (tr.oct & 4u) pm = ((pm & 0x0Fu) << 4) | (pm >> 4);
         if ((tr.g_pend & 0xFFu) != 0u) {
             const uint2 e = make_uint2(tr.g_hdr, tr.g_pend);
             if (!SPILL || tr.sp < lds_depth) stack[tr.sp * stack_stride] = e;
@@ -131,27 +138,27 @@ CRT_DEV void wide_visit(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_
             tr.sp++;
         }
         tr.g_hdr = f2u(h.w);
-        tr.g_pend = (node << 8) | pm;
+        tr.g_pend = (node << 8) | m;
     }
 }
 
 // Inner step: tr.cur is a node index.
 template <bool COUNT, bool SPILL>
-CRT_DEV bool wide_inner(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_t stack_stride, uint2 *spill, int lds_depth, Counts &cnt) {
+CRT_DEV bool wide_inner(const float4 *nodes, const uint8_t *order, WideTrav &tr, uint2 *stack, uint32_t stack_stride, uint2 *spill, int lds_depth, Counts &cnt) {
     wide_visit<COUNT, SPILL>(nodes, tr, stack, stack_stride, spill, lds_depth, cnt);
-    return wide_advance<SPILL>(nodes, tr, stack, stack_stride, spill, lds_depth);
+    return wide_advance<SPILL>(nodes, order, tr, stack, stack_stride, spill, lds_depth);
 }
 
 // Leaf step: tr.cur is a tagged leaf entry.
 template <bool COUNT, bool SPILL>
-CRT_DEV bool wide_leaf(const DeviceScene &sc, WideTrav &tr, const uint2 *stack, uint32_t stack_stride, const uint2 *spill, int lds_depth, Counts &cnt) {
+CRT_DEV bool wide_leaf(const DeviceScene &sc, const uint8_t *order, WideTrav &tr, const uint2 *stack, uint32_t stack_stride, const uint2 *spill, int lds_depth, Counts &cnt) {
     const uint32_t e = tr.cur;
     const uint32_t kind = (e >> 29) & 3u, n = ((e >> 26) & 7u) + 1u, first = e & (kMaxLeafLink - 1u);
     if (kind != 3u) {                                   // 3 = empty slot (a box test can only reach it through rounding)
         test_leaf<COUNT>(sc, tr.o, tr.d, first, (kind << 28) | n, tr.best_t, tr.best_id, cnt);
         tr.tfar = tr.best_t * 1.000004f;                // relative pad (2^-18) on the far bound
     }
-    return wide_advance<SPILL>(sc.wide, tr, stack, stack_stride, spill, lds_depth);
+    return wide_advance<SPILL>(sc.wide, order, tr, stack, stack_stride, spill, lds_depth);
 }
 
 }  // namespace crt

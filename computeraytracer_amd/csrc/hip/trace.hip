@@ -251,8 +251,8 @@ template <bool SPILL> struct LaneTrav<false, SPILL> {          // sibling-pair B
     Traversal tr;
     CRT_DEV void begin(V3 o, V3 d) { trav_begin(tr, o, d); }
     CRT_DEV bool at_leaf() const { return (tr.cur & kLeafTag) != 0; }
-    template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, Entry *stack, Entry *spill, int depth, Counts &c) { return trav_inner<COUNT>(sc, tr, stack, 256, spill, depth, c); }
-    template <bool COUNT> CRT_DEV bool leaf(const DeviceScene &sc, Entry *stack, Entry *spill, int depth, Counts &c) { return trav_leaf<COUNT>(sc, tr, stack, 256, spill, depth, c); }
+    template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, const uint8_t *, Entry *stack, Entry *spill, int depth, Counts &c) { return trav_inner<COUNT>(sc, tr, stack, 256, spill, depth, c); }
+    template <bool COUNT> CRT_DEV bool leaf(const DeviceScene &sc, const uint8_t *, Entry *stack, Entry *spill, int depth, Counts &c) { return trav_leaf<COUNT>(sc, tr, stack, 256, spill, depth, c); }
 };
 template <bool SPILL> struct LaneTrav<true, SPILL> {           // 8-wide quantised BVH (intersect_wide.h)
     using Entry = uint2;
@@ -260,8 +260,8 @@ template <bool SPILL> struct LaneTrav<true, SPILL> {           // 8-wide quantis
     WideTrav tr;
     CRT_DEV void begin(V3 o, V3 d) { wide_begin(tr, o, d); }
     CRT_DEV bool at_leaf() const { return (tr.cur & kLeafTag) != 0; }
-    template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_inner<COUNT, SPILL>(sc.wide, tr, stack, 256, spill, depth, c); }
-    template <bool COUNT> CRT_DEV bool leaf(const DeviceScene &sc, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_leaf<COUNT, SPILL>(sc, tr, stack, 256, spill, depth, c); }
+    template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, const uint8_t *order, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_inner<COUNT, SPILL>(sc.wide, order, tr, stack, 256, spill, depth, c); }
+    template <bool COUNT> CRT_DEV bool leaf(const DeviceScene &sc, const uint8_t *order, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_leaf<COUNT, SPILL>(sc, order, tr, stack, 256, spill, depth, c); }
 };
 static_assert(kLdsStack * 4 == kWideLds * 8, "both stack layouts use the same LDS block");
 
@@ -271,6 +271,8 @@ static_assert(kLdsStack * 4 == kWideLds * 8, "both stack layouts use the same LD
 template <bool COUNT, bool WIDE, bool SPILL>
 __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene sc, WfQueues q, uint32_t bounce, unsigned long long dead, DeviceStats *stats) {
     __shared__ uint2 s_stack[kWideLds * 256];
+    __shared__ uint8_t s_order[WIDE ? kWideOrderBytes : 4];
+    if (WIDE) { wide_order_table(s_order, threadIdx.x, blockDim.x); __syncthreads(); }
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t *counts = q.counts + bounce * kShards * kCtrStride;
     uint32_t *cursors = q.cursors + bounce * kShards * kCtrStride;
@@ -354,10 +356,10 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
         bool more = true;
         if (n_leaf >= q.leaf_lanes || !any_inner) {
             if (COUNT) { c_leaf++; c_leaf_lanes += n_leaf; }
-            if (at_leaf) more = lt.template leaf<COUNT>(sc, stack, spill, lds_depth, cnt);
+            if (at_leaf) more = lt.template leaf<COUNT>(sc, s_order, stack, spill, lds_depth, cnt);
         } else {
             if (COUNT) { c_inner++; c_inner_lanes += (uint32_t)__popcll(__ballot(busy && !at_leaf)); }
-            if (busy && !at_leaf) more = lt.template inner<COUNT>(sc, stack, spill, lds_depth, cnt);
+            if (busy && !at_leaf) more = lt.template inner<COUNT>(sc, s_order, stack, spill, lds_depth, cnt);
         }
         if (!more) {
             q.hit[slot] = make_uint2(f2u(lt.tr.best_t), lt.tr.best_id);
