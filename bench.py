@@ -213,10 +213,10 @@ def main():
 
     if rank == 0:
         mrays = rays / elapsed / 1e6
-        # bytes/ray of the whole pipeline = 32 V + 48 T + 128 (queue entry written + read) + 32 / D (accumulation)
+        # bytes/ray of the whole pipeline = 32 V + 48 T + 96 (48-byte queue entry written + read) + 32 / D (accumulation)
         # node bytes per box tested: 32 (pair BVH: 32-byte nodes) or 8 (8-wide quantised nodes: 64 bytes loaded per 8 boxes)
         node_b = 8.0 if wide else 32.0
-        bytes_per_ray = node_b * V + 48.0 * T + (128.0 if tracer == abi.TRACER_WAVEFRONT else 0.0) + 32.0 / D
+        bytes_per_ray = node_b * V + 48.0 * T + (96.0 if tracer == abi.TRACER_WAVEFRONT else 0.0) + 32.0 / D
         rank_rays = float(st.rays)
         if tracer == abi.TRACER_WAVEFRONT and st.last_extend_launches:
             # dominant kernel k_wf_extend: of that figure it moves 32 V + 48 T + 32 (ray read) + 8 (hit record written)

@@ -77,7 +77,7 @@ struct DeviceStats {
 
 struct WavefrontState {
     uint32_t capacity = 0;           // paths the queues can hold
-    DeviceBuffer ray_o[2], ray_d[2], thr[2], emi[2], hit, counters, pass;
+    DeviceBuffer ray_o[2], ray_d[2], thr[2], hit, counters, pass;
     bool time_kernels = false;
     std::vector<hipEvent_t> ev;      // start/stop pairs around extend launches
     size_t ev_used = 0;

@@ -317,6 +317,7 @@ int crt_render(crt_context *ctx, const crt_scene_params *params, uint32_t first_
         const double per_iter = (double)ctx->n_local_bands * 8.0 * ctx->grid_w;
         batch = per_iter > 0.0 ? (uint32_t)(target / per_iter) : 1u;
         batch = batch < 1u ? 1u : batch > 64u ? 64u : batch;
+        if ((size_t)ctx->local_rows * ctx->cfg.width >= (1u << 26) - 1u) batch = 1;      // ray_d.w packs batch index << 26 | pixel slot
     }
     for (uint32_t i = 0; i < n_iterations && rc == CRT_OK; i += batch) {
         const uint32_t nb = n_iterations - i < batch ? n_iterations - i : batch;

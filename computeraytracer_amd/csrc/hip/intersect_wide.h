@@ -3,8 +3,9 @@
 // One step = four 16-byte loads (header + 48 quantised plane bytes), eight slab tests, one 8-bit hit mask.
 // The hit children of a node wait as ONE stack entry {child_base | imask, node | pending mask}.  The visiting order of
 // a group is slot ^ ray octant ascending; "next child" of a pending mask is one byte read from a 2 KiB LDS table
-// indexed by (octant, mask) (wide_order_table), cheaper than permuting the mask.  The top entry lives in registers.  Inner children are addressed as child_base + popcount(imask below slot); the link of a
-// leaf slot is loaded only when that slot is actually taken.
+// indexed by (octant, mask) (wide_order_table), cheaper than permuting the mask.  The top entry lives in registers.  Inner children are
+// addressed as child_base + popcount(imask below slot); the link of a leaf slot is loaded only when that slot is
+// actually taken.
 //
 // Conservativeness.  The planes of a child box are the real numbers P = origin + q * 2^e.  A step evaluates
 // t = q * A + B with A = (1/d) * 2^e (exact) and B = fma(origin, 1/d, -(o * 1/d)); the rounding of 1/d, of o * 1/d,

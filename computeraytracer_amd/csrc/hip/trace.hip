@@ -149,7 +149,9 @@ bool launch_megakernel(hipStream_t stream, const DeviceSceneHost &sch, const Fra
 //
 //   queue entry (64 B, SoA over four float4 arrays, two queues used ping-pong):
 //     ray_o = {origin.xyz, -}            ray_d = {direction.xyz, pixel slot in the packed band buffer}
-//     thr   = {color.rgb, rng word 0}    emi   = {emittedColor.rgb, rng word 1}
+//     thr   = {color.rgb, rng word 1};  ray_o's spare lane holds rng word 0, ray_d's the pixel slot | batch index << 26.
+//     ray_color's emittedColor is not carried: a path that meets an emitter ends there (scatter() is false for a light,
+//     compute.comp:416-418), so it is zero for every path still in a queue.
 //   hit[i] = {t, id} of queue entry i (8 B), written by extend, read by shade.
 //
 // The queue is split into kShards sub-queues (contiguous runs of 8x8 tiles).  A path never leaves its
@@ -170,7 +172,7 @@ constexpr uint32_t kCtrStride = 64;    // one counter per 256 bytes: neighbourin
 constexpr uint32_t kFetchBatches = 4;  // at most this many 64-ray batches per work-fetch atomic
 
 struct WfQueues {
-    float4 *ray_o[2], *ray_d[2], *thr[2], *emi[2];
+    float4 *ray_o[2], *ray_d[2], *thr[2];
     uint2 *hit;
     uint32_t *counts;       // [kMaxBounces + 1][kShards] live paths entering bounce b in sub-queue s
     uint32_t *cursors;      // [kMaxBounces][kShards]     extend's work-fetch cursor
@@ -182,6 +184,7 @@ struct WfQueues {
     uint32_t lds_depth;                    // LDS stack entries per lane (lower only with CRT_FLAG_DEBUG_SMALL_STACK)
 };
 
+constexpr uint32_t kPixBits = 26;               // ray_d.w = batch index << 26 | pixel slot (batches need < 2^26 - 1 pixel slots)
 constexpr uint32_t kDeadPixel = 0xFFFFFFFFu;   // queue entry of a lane outside the rendered grid (ragged sizes only)
 
 __global__ void k_wf_init(WfQueues q, uint32_t n_tiles, unsigned long long n_active, DeviceStats *stats) {
@@ -221,10 +224,9 @@ __global__ __launch_bounds__(256) void k_wf_generate(Frame f, WfQueues q) {
     V3 o, d;
     camera_get_ray(cam, u, v, rng, o, d);
     const uint64_t rs = rng.pack();
-    q.ray_o[0][slot] = make_float4(o.x, o.y, o.z, u2f(it));
-    q.ray_d[0][slot] = make_float4(d.x, d.y, d.z, u2f(prow * f.width + x));
-    q.thr[0][slot] = make_float4(1.0f, 1.0f, 1.0f, u2f((uint32_t)rs));
-    q.emi[0][slot] = make_float4(0.0f, 0.0f, 0.0f, u2f((uint32_t)(rs >> 32)));
+    q.ray_o[0][slot] = make_float4(o.x, o.y, o.z, u2f((uint32_t)rs));
+    q.ray_d[0][slot] = make_float4(d.x, d.y, d.z, u2f((it << kPixBits) | (prow * f.width + x)));
+    q.thr[0][slot] = make_float4(1.0f, 1.0f, 1.0f, u2f((uint32_t)(rs >> 32)));
 }
 
 // Home sub-queue of a wave: blocks b and b + 8 share an XCD (and its L2), so the waves of one XCD start on
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene s
         uint32_t *out_count = q.counts + ((bounce + 1) * kShards + s) * kCtrStride;
         const uint32_t i = base + lane;
         bool alive = false;
-        V3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), color = mk3(0, 0, 0), emitted = mk3(0, 0, 0);
+        V3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), color = mk3(0, 0, 0);
         uint32_t pix = kDeadPixel, it = 0;
         Rng<RNGM> rng;
         if (i < n) {
@@ -412,12 +414,13 @@ __global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene s
             float4 d4 = q.ray_d[in][slot];
             pix = f2u(d4.w);
             if (pix != kDeadPixel) {
-                float4 o4 = q.ray_o[in][slot], c4 = q.thr[in][slot], e4 = q.emi[in][slot];
+                float4 o4 = q.ray_o[in][slot], c4 = q.thr[in][slot];
                 uint2 h = q.hit[slot];
                 o = mk3(o4.x, o4.y, o4.z); d = mk3(d4.x, d4.y, d4.z);
-                color = mk3(c4.x, c4.y, c4.z); emitted = mk3(e4.x, e4.y, e4.z);
-                it = f2u(o4.w);
-                rng.unpack((uint64_t)f2u(c4.w) | ((uint64_t)f2u(e4.w) << 32), ((uint64_t)(uint32_t)(f.iter0 + (float)it) << 1) | 1u);
+                color = mk3(c4.x, c4.y, c4.z);
+                V3 emitted = mk3(0.0f, 0.0f, 0.0f);      // see the queue-entry comment
+                it = pix >> kPixBits; pix &= (1u << kPixBits) - 1u;
+                rng.unpack((uint64_t)f2u(o4.w) | ((uint64_t)f2u(c4.w) << 32), ((uint64_t)(uint32_t)(f.iter0 + (float)it) << 1) | 1u);
                 const float t = u2f(h.x); const uint32_t id = h.y;
                 if (bounce == 0 && it + 1 == f.n_batch) hit_ids[pix] = id;
                 V3 pass = mk3(0.0f, 0.0f, 0.0f);
@@ -438,10 +441,9 @@ __global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene s
         if (alive) {
             const uint32_t slot = s * q.shard_cap + obase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             const uint64_t rs = rng.pack();
-            q.ray_o[out][slot] = make_float4(o.x, o.y, o.z, u2f(it));
-            q.ray_d[out][slot] = make_float4(d.x, d.y, d.z, u2f(pix));
-            q.thr[out][slot] = make_float4(color.x, color.y, color.z, u2f((uint32_t)rs));
-            q.emi[out][slot] = make_float4(emitted.x, emitted.y, emitted.z, u2f((uint32_t)(rs >> 32)));
+            q.ray_o[out][slot] = make_float4(o.x, o.y, o.z, u2f((uint32_t)rs));
+            q.ray_d[out][slot] = make_float4(d.x, d.y, d.z, u2f((it << kPixBits) | pix));
+            q.thr[out][slot] = make_float4(color.x, color.y, color.z, u2f((uint32_t)(rs >> 32)));
         }
     }
 }
@@ -482,6 +484,7 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     Frame f = make_frame(fs, params);
     if (f.n_tiles == 0) return true;
     if (n_batch < 1 || n_batch > kBatchMax) { err = "wavefront batch must hold 1..64 iterations"; return false; }
+    if (n_batch > 1 && accum_pixels >= (1u << kPixBits) - 1u) { err = "wavefront batches need fewer than 2^26 - 1 pixel slots"; return false; }
     f.n_batch = n_batch;
     if (seeds) for (uint32_t b = 0; b < n_batch; b++) f.seeds[b] = seeds[b];
     const uint32_t n_vt = f.n_tiles * n_batch;
@@ -503,7 +506,7 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     if (wf.capacity < cap) {
         for (int k = 0; k < 2; k++) {
             if (!ensure_dev(wf.ray_o[k], (size_t)cap * 16, err) || !ensure_dev(wf.ray_d[k], (size_t)cap * 16, err) ||
-                !ensure_dev(wf.thr[k], (size_t)cap * 16, err) || !ensure_dev(wf.emi[k], (size_t)cap * 16, err)) return false;
+                !ensure_dev(wf.thr[k], (size_t)cap * 16, err)) return false;
         }
         if (!ensure_dev(wf.hit, (size_t)cap * 8, err) || !ensure_dev(wf.counters, (size_t)(2 * kMaxBounces + 1) * kShards * kCtrStride * 4, err)) return false;
         wf.capacity = cap;
@@ -511,7 +514,7 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     if (!ensure_dev(wf.pass, (size_t)n_batch * accum_pixels * 16, err)) return false;
     for (int k = 0; k < 2; k++) {
         q.ray_o[k] = (float4 *)wf.ray_o[k].ptr; q.ray_d[k] = (float4 *)wf.ray_d[k].ptr;
-        q.thr[k] = (float4 *)wf.thr[k].ptr; q.emi[k] = (float4 *)wf.emi[k].ptr;
+        q.thr[k] = (float4 *)wf.thr[k].ptr;
     }
     q.hit = (uint2 *)wf.hit.ptr;
     q.counts = (uint32_t *)wf.counters.ptr;
@@ -565,7 +568,7 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
 }
 
 void free_wavefront(WavefrontState &wf) {
-    DeviceBuffer *all[] = {&wf.ray_o[0], &wf.ray_o[1], &wf.ray_d[0], &wf.ray_d[1], &wf.thr[0], &wf.thr[1], &wf.emi[0], &wf.emi[1],
+    DeviceBuffer *all[] = {&wf.ray_o[0], &wf.ray_o[1], &wf.ray_d[0], &wf.ray_d[1], &wf.thr[0], &wf.thr[1],
                            &wf.hit, &wf.counters, &wf.pass};
     for (DeviceBuffer *b : all) if (b->ptr) { hipError_t e = hipFree(b->ptr); (void)e; b->ptr = nullptr; b->bytes = 0; }
     for (hipEvent_t e : wf.ev) { hipError_t r = hipEventDestroy(e); (void)r; }
