@@ -369,3 +369,16 @@ def test_stack_overflow_path(ctx, golden_dir, bvh):
     img, ids, ps = _gpu_render(ctx, scene, w, h, 2, bvh=bvh, tracer=abi.TRACER_WAVEFRONT, flags=abi.FLAG_DEBUG_SMALL_STACK)
     ref_img, ref_ids, _ = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_FAST)
     assert np.array_equal(ids, ref_ids) and np.array_equal(img.view(np.uint32), ref_img.view(np.uint32))
+
+
+@pytest.mark.parametrize("name,w,h,n_iter", [("voxel_city", 3840, 2160, 1), ("monkey", 1920, 1080, 2), ("cirno", 1920, 1080, 2)],
+                         ids=["lost_empire-standin-4K", "monkey-1080p", "cirno-1080p"])
+def test_full_size_configs_bit_exact_vs_oracle(ctx, golden_dir, name, w, h, n_iter):
+    # BASELINE.json configs 2-4 at their real resolutions (fewer iterations: the oracle runs ~9 Mrays/s): the default
+    # product path (wavefront tracer, SAH-refined tree collapsed to 8-wide nodes, batched iterations) against the oracle
+    scene = abi.builtin_scene(name, w, h, golden_dir)
+    img, ids, ps = _gpu_render(ctx, scene, w, h, n_iter, bvh=abi.BVH_SAH_REFINE | abi.BVH_WIDE, tracer=abi.TRACER_WAVEFRONT)
+    ref_img, ref_ids, cnt = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_FAST)
+    assert (ids != ref_ids).sum() == 0
+    assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32))
+    assert cnt.rays > w * h * n_iter
