@@ -103,6 +103,7 @@ def _load():
         "crt_loop_counters_read": (i32, [vp, vp, u32]),
         "crt_bvh_read": (i32, [vp, vp, P(u32), vp, vp, vp]),
         "crt_bvh_wide_read": (i32, [vp, vp, P(u32), P(u32)]),
+        "crt_debug_boxes_upload": (i32, [vp, vp, u32]),
         "crt_camera_init": (None, [vp, P(f32), P(f32), f32, f32, f32, f32]),
         "crt_frame_seeds": (None, [u32, u32, vp]),
         "crt_quad_init": (None, [vp, P(f32), P(f32), P(f32), u32]),
@@ -370,3 +371,9 @@ class Context:
         nodes = np.zeros((n.value, 32), dtype=np.uint32)
         self._check(lib.crt_bvh_wide_read(self._h, _ptr(nodes), C.byref(n), C.byref(lv)), "crt_bvh_wide_read")
         return nodes, lv.value
+
+    def debug_boxes_upload(self, ref_nodes):
+        """ref_nodes: numpy array of ref_node_dtype (the reference's BVHNode array) for the AABB-outline debug view."""
+        ref_nodes = np.ascontiguousarray(ref_nodes, dtype=ref_node_dtype)
+        self._keep_boxes = ref_nodes
+        self._check(lib.crt_debug_boxes_upload(self._h, _ptr(ref_nodes), len(ref_nodes)), "crt_debug_boxes_upload")

@@ -21,7 +21,8 @@ struct crt_context {
     crt_config cfg{};
     bool configured = false, have_scene = false, have_bvh = false, timing_pending = false;
     // scene (reference layouts, input order)
-    DeviceBuffer spheres, quads, tris, tris_rest, materials, tex0;
+    DeviceBuffer spheres, quads, tris, tris_rest, materials, tex0, dbg_boxes;
+    uint32_t n_dbg_boxes = 0;
     uint32_t n_spheres = 0, n_quads = 0, n_tris = 0, n_materials = 0, n_textures = 0, tex0_w = 0, tex0_h = 0;
     bool animated = false;
     BuildState build;
@@ -79,6 +80,7 @@ DeviceSceneHost scene_view(const crt_context *ctx) {
     s.spheres = (const crt_sphere *)ctx->spheres.ptr; s.quads = (const crt_quad *)ctx->quads.ptr; s.tris = (const crt_tri *)ctx->tris.ptr;
     s.materials = (const crt_material *)ctx->materials.ptr;
     s.tex0 = (const uint8_t *)ctx->tex0.ptr; s.tex0_w = ctx->tex0_w; s.tex0_h = ctx->tex0_h; s.n_textures = ctx->n_textures;
+    s.dbg_boxes = ctx->n_dbg_boxes ? ctx->dbg_boxes.ptr : nullptr; s.n_dbg_boxes = ctx->n_dbg_boxes;
     return s;
 }
 
@@ -165,7 +167,7 @@ void crt_destroy(crt_context *ctx) {
     if (!ctx) return;
     if (hipSetDevice(ctx->device) == hipSuccess) {
         hipError_t e = hipStreamSynchronize(ctx->stream); (void)e;
-        DeviceBuffer *all[] = {&ctx->spheres, &ctx->quads, &ctx->tris, &ctx->tris_rest, &ctx->materials, &ctx->tex0, &ctx->accum, &ctx->hit_ids, &ctx->stats};
+        DeviceBuffer *all[] = {&ctx->spheres, &ctx->quads, &ctx->tris, &ctx->tris_rest, &ctx->materials, &ctx->tex0, &ctx->dbg_boxes, &ctx->accum, &ctx->hit_ids, &ctx->stats};
         for (DeviceBuffer *b : all) release(*b);
         free_build_state(ctx->build);
         free_wavefront(ctx->wf);
@@ -219,7 +221,7 @@ int crt_scene_upload(crt_context *ctx, const crt_scene_desc *s) {
     for (uint32_t i = 0; i < s->n_textures; i++)
         if (!s->textures[i].rgba8 || s->textures[i].width == 0 || s->textures[i].height == 0) return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload: empty texture");
     CTX_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->have_scene = false; ctx->have_bvh = false; ctx->animated = false;
+    ctx->have_scene = false; ctx->have_bvh = false; ctx->animated = false; ctx->n_dbg_boxes = 0;
     if ((rc = upload(ctx, ctx->spheres, s->spheres, (size_t)s->n_spheres * sizeof(crt_sphere)))) return rc;
     if ((rc = upload(ctx, ctx->quads, s->quads, (size_t)s->n_quads * sizeof(crt_quad)))) return rc;
     if ((rc = upload(ctx, ctx->tris, s->tris, (size_t)s->n_tris * sizeof(crt_tri)))) return rc;
@@ -449,6 +451,17 @@ int crt_bvh_read(crt_context *ctx, crt_bvh_node *nodes, uint32_t *n_nodes, uint3
     if (sphere_ids && ctx->n_spheres) CTX_HIP(hipMemcpy(sphere_ids, ctx->build.sphere_ids.ptr, (size_t)ctx->n_spheres * 4, hipMemcpyDeviceToHost));
     if (quad_ids && ctx->n_quads) CTX_HIP(hipMemcpy(quad_ids, ctx->build.quad_ids.ptr, (size_t)ctx->n_quads * 4, hipMemcpyDeviceToHost));
     if (tri_ids && ctx->n_tris) CTX_HIP(hipMemcpy(tri_ids, ctx->build.tri_ids.ptr, (size_t)ctx->n_tris * 4, hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt_debug_boxes_upload(crt_context *ctx, const crt_ref_bvh_node *nodes, uint32_t n_nodes) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!ctx->have_scene) return fail(ctx, CRT_ERR_INVALID, "crt_debug_boxes_upload: no scene uploaded");
+    if (n_nodes && !nodes) return fail(ctx, CRT_ERR_INVALID, "crt_debug_boxes_upload: null nodes");
+    CTX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->n_dbg_boxes = 0;
+    if ((rc = upload(ctx, ctx->dbg_boxes, nodes, (size_t)n_nodes * sizeof(crt_ref_bvh_node)))) return rc;
+    ctx->n_dbg_boxes = n_nodes;
     return CRT_OK;
 }
 

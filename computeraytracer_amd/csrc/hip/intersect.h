@@ -29,6 +29,8 @@ struct DeviceScene {
     const uint8_t *tex0;        // textures[0], RGBA8 rows top-down (the shader only ever samples index 0, compute.comp:387)
     uint32_t tex0_w, tex0_h;
     uint32_t n_textures;
+    const float4 *dbg_boxes;    // crt_debug_boxes_upload: the reference's BVHNode array (64-byte stride), or null
+    uint32_t n_dbg_boxes;
 };
 
 #ifndef CRT_LDS_STACK

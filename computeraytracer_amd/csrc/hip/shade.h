@@ -98,6 +98,29 @@ CRT_DEV bool shade_hit(const DeviceScene &sc, V3 &o, V3 &d, float t, uint32_t id
     return true;
 }
 
+// hit_aabb, compute.comp:214-225, with t = INFINITY (the traversal has its own fused slab test in intersect.h).
+CRT_DEV bool ref_hit_aabb(V3 o, V3 inv, V3 mn, V3 mx) {
+    V3 tMin = (mn - o) * inv, tMax = (mx - o) * inv;
+    V3 t0 = mk3(__builtin_fminf(tMin.x, tMax.x), __builtin_fminf(tMin.y, tMax.y), __builtin_fminf(tMin.z, tMax.z));
+    V3 t1 = mk3(__builtin_fmaxf(tMin.x, tMax.x), __builtin_fmaxf(tMin.y, tMax.y), __builtin_fmaxf(tMin.z, tMax.z));
+    float tNearest = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(t0.x, t0.y), t0.z), kTNear);
+    float tFurthest = __builtin_fminf(__builtin_fminf(__builtin_fminf(t1.x, t1.y), t1.z), __builtin_inff());
+    return tNearest < tFurthest;
+}
+
+// "Render AABB Option" of ray_color (compute.comp:427-436, R15): true when the camera ray crosses the 0.005-wide
+// outline of any box of the reference's BVH array (supplied by the caller, crt_debug_boxes_upload); the sample is white.
+CRT_DEV bool aabb_outline(const DeviceScene &sc, V3 o, V3 d) {
+    V3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    for (uint32_t i = 0; i < sc.n_dbg_boxes; i++) {
+        float4 a = sc.dbg_boxes[4 * (size_t)i], b = sc.dbg_boxes[4 * (size_t)i + 1];
+        V3 mn = mk3(a.x, a.y, a.z), mx = mk3(b.x, b.y, b.z);
+        V3 mn2 = mk3(mn.x + 0.005f, mn.y + 0.005f, mn.z + 0.005f), mx2 = mk3(mx.x - 0.005f, mx.y - 0.005f, mx.z - 0.005f);
+        if (ref_hit_aabb(o, inv, mn, mx) && !ref_hit_aabb(o, inv, mn2, mx2)) return true;
+    }
+    return false;
+}
+
 // compute.comp:443-449
 CRT_DEV V3 shade_miss(const crt_scene_params &p, V3 d, V3 color) {
     if (p.backgroundColor[0] != -1.0f || p.backgroundColor[1] != -1.0f || p.backgroundColor[2] != -1.0f)

@@ -39,6 +39,7 @@ static DeviceScene to_device_scene(const DeviceSceneHost &h) {
     d.sphere_ids = h.sphere_ids; d.quad_ids = h.quad_ids;
     d.spheres = h.spheres; d.quads = h.quads; d.tris = h.tris; d.materials = h.materials;
     d.tex0 = h.tex0; d.tex0_w = h.tex0_w; d.tex0_h = h.tex0_h; d.n_textures = h.n_textures;
+    d.dbg_boxes = (const float4 *)h.dbg_boxes; d.n_dbg_boxes = h.n_dbg_boxes;
     return d;
 }
 
@@ -100,7 +101,9 @@ __global__ __launch_bounds__(256) void k_megakernel(DeviceScene sc, Frame f, flo
         // ray_color(), :438-457
         V3 color = mk3(1.0f, 1.0f, 1.0f), emitted = mk3(0.0f, 0.0f, 0.0f), pass = mk3(0.0f, 0.0f, 0.0f);
         uint32_t primary = kIdMiss;
-        for (uint32_t depth = 0; depth < f.max_bounces; depth++) {
+        const bool outline = cam.shouldRenderAABB != 0u && aabb_outline(sc, o, d);       // R15
+        if (outline) pass = mk3(1.0f, 1.0f, 1.0f);
+        for (uint32_t depth = 0; depth < f.max_bounces && !outline; depth++) {
             float t; uint32_t id; Counts cnt = {0, 0};
             closest_hit<COUNT>(sc, o, d, s_stack + threadIdx.x, 256, t, id, cnt);
             rays++;
@@ -201,7 +204,7 @@ __global__ void k_wf_init(WfQueues q, uint32_t n_tiles, unsigned long long n_act
 }
 
 template <int RNGM>
-__global__ __launch_bounds__(256) void k_wf_generate(Frame f, WfQueues q) {
+__global__ __launch_bounds__(256) void k_wf_generate(DeviceScene sc, Frame f, WfQueues q, float4 *pass_buf, uint32_t pass_stride, uint32_t *hit_ids, DeviceStats *stats) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t vt = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;      // virtual tile: iteration-major over the batch
     if (vt >= f.n_tiles * f.n_batch) return;
@@ -223,6 +226,19 @@ __global__ __launch_bounds__(256) void k_wf_generate(Frame f, WfQueues q) {
     float u = ((float)x + ox) / (float)f.width, v = ((float)y + oy) / (float)f.height;
     V3 o, d;
     camera_get_ray(cam, u, v, rng, o, d);
+    if (cam.shouldRenderAABB != 0u) {          // R15 debug view: a sample on a box outline is white and traces nothing
+        const bool outline = aabb_outline(sc, o, d);
+        const unsigned long long killed = (unsigned long long)__popcll(__ballot(outline));
+        if (killed && (unsigned long long)__ffsll((long long)__ballot(outline)) - 1ull == lane) atomicAdd(&stats->rays, 0ull - killed);   // extend counts every queue entry that is not a ragged-edge lane
+        if (outline) {
+            const uint32_t pix = prow * f.width + x;
+            pass_buf[(size_t)it * pass_stride + pix] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            if (it + 1 == f.n_batch) hit_ids[pix] = kIdMiss;
+            q.ray_o[0][slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            q.ray_d[0][slot] = make_float4(0.0f, 0.0f, 1.0f, u2f(kDeadPixel));
+            return;
+        }
+    }
     const uint64_t rs = rng.pack();
     q.ray_o[0][slot] = make_float4(o.x, o.y, o.z, u2f((uint32_t)rs));
     q.ray_d[0][slot] = make_float4(d.x, d.y, d.z, u2f((it << kPixBits) | (prow * f.width + x)));
@@ -539,8 +555,8 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     const dim3 sgrid(env_sgrid ? env_sgrid : nb);
     const bool pcg = fs.rng_mode != CRT_RNG_REF;
     hipLaunchKernelGGL(k_wf_init, dim3(1), dim3(256), 0, stream, q, n_vt, n_active, stats);
-    if (pcg) hipLaunchKernelGGL((k_wf_generate<1>), gen_grid, block, 0, stream, f, q);
-    else hipLaunchKernelGGL((k_wf_generate<0>), gen_grid, block, 0, stream, f, q);
+    if (pcg) hipLaunchKernelGGL((k_wf_generate<1>), gen_grid, block, 0, stream, sc, f, q, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
+    else hipLaunchKernelGGL((k_wf_generate<0>), gen_grid, block, 0, stream, sc, f, q, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
     for (uint32_t b = 0; b < f.max_bounces; b++) {
         const unsigned long long dead_b = b == 0 ? dead : 0ull;
         if (wf.time_kernels) {

@@ -139,6 +139,12 @@ int crt_bvh_read(crt_context *ctx, crt_bvh_node *nodes, uint32_t *n_nodes,
  * Build-only diagnostic, no counterpart in the reference. */
 int crt_bvh_wide_read(crt_context *ctx, void *nodes, uint32_t *n_nodes, uint32_t *n_levels);
 
+/* The AABB-outline debug view (camera.shouldRenderAABB, compute.comp:427-436) draws the boxes of the REFERENCE's
+ * BVHNode array (set 0 binding 2, vk_engine.cpp:1203), which the device-side build does not produce.  A caller that
+ * wants the view supplies that array (64-byte nodes, T1 layout; only the boxes are read); it belongs to the current
+ * scene and is dropped by crt_scene_upload.  Without it the flag draws nothing. */
+int crt_debug_boxes_upload(crt_context *ctx, const crt_ref_bvh_node *nodes, uint32_t n_nodes);
+
 /* ---- host-side helpers (no GPU needed) --------------------------------- */
 
 /* Camera::Camera + Camera::calculateProperties (raytracing/src/camera.cpp:3-12,40-62):

@@ -382,3 +382,38 @@ def test_full_size_configs_bit_exact_vs_oracle(ctx, golden_dir, name, w, h, n_it
     assert (ids != ref_ids).sum() == 0
     assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32))
     assert cnt.rays > w * h * n_iter
+
+
+@pytest.mark.parametrize("tracer", [abi.TRACER_MEGAKERNEL, abi.TRACER_WAVEFRONT], ids=["megakernel", "wavefront"])
+@pytest.mark.parametrize("name", ["book1", "corne"])
+def test_aabb_outline_debug_view(ctx, name, tracer):
+    # R15, compute.comp:427-436: the view draws the REFERENCE's BVH boxes, so the caller supplies that node array (here:
+    # the oracle's restatement of the reference builder, as test data); the oracle renders the same view in its
+    # reference-traversal mode
+    w, h, n = 96, 56, 2
+    scene = abi.builtin_scene(name, w, h)
+    scene.params = scene.params.copy()
+    scene.params["camera"]["shouldRenderAABB"] = 1
+    ref_nodes, _, _, _ = orc.ref_bvh(scene)
+    ctx.configure(w, h, tracer=tracer)
+    ctx.upload(scene)
+    ctx.debug_boxes_upload(ref_nodes)
+    ctx.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE)
+    ctx.stats_reset()
+    ps, seeds = _params(scene, n)
+    ctx.render(ps[0], 1, seeds); ctx.sync()
+    img, ids = ctx.image(), ctx.hit_ids()
+    ref_img, ref_ids, cnt = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_REF)
+    assert np.array_equal(ids, ref_ids)
+    assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32))
+    white = (ref_img[..., :3] == n).all(axis=2).sum()
+    assert 0 < white < w * h                     # some samples are outline, some are not
+    assert ctx.stats().rays == cnt.rays
+    # without the boxes the flag draws nothing (configure again: the shader's reset, cum += -cum + pass at iteration 1,
+    # is only exact on a zero image)
+    ctx.configure(w, h, tracer=tracer)
+    ctx.upload(scene); ctx.build()
+    ctx.render(ps[0], 1, seeds); ctx.sync()
+    scene.params["camera"]["shouldRenderAABB"] = 0
+    plain, _, _ = orc.render(scene, _params(scene, n)[0], w, h, flags=orc.TRAVERSE_FAST)
+    assert np.array_equal(ctx.image().view(np.uint32), plain.view(np.uint32))
