@@ -181,7 +181,8 @@ void SceneBuilder::push_box(f3c a, f3c b, uint32_t mat) {
     f3c mn = {std::fmin(a.x, b.x), std::fmin(a.y, b.y), std::fmin(a.z, b.z)};
     f3c mx = {std::fmax(a.x, b.x), std::fmax(a.y, b.y), std::fmax(a.z, b.z)};
     f3c dx = {mx.x - mn.x, 0, 0}, dy = {0, mx.y - mn.y, 0}, dz = {0, 0, mx.z - mn.z};
-    f3c ndx = {-dx.x, 0, 0}, ndz = {0, 0, -dz.z};
+    // glm's unary minus negates every component: the zeros of -dx / -dz are negative zeros (primitives.h:112-115)
+    f3c ndx = {-dx.x, -0.0f, -0.0f}, ndz = {-0.0f, -0.0f, -dz.z};
     std::vector<uint32_t> ids;
     ids.push_back(add_quad({mn.x, mn.y, mx.z}, dx, dy, mat));    // front
     ids.push_back(add_quad({mx.x, mn.y, mx.z}, ndz, dy, mat));   // right
