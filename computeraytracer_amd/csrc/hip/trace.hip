@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene s
                 o = mk3(o4.x, o4.y, o4.z); d = mk3(d4.x, d4.y, d4.z);
                 color = mk3(c4.x, c4.y, c4.z);
                 V3 emitted = mk3(0.0f, 0.0f, 0.0f);      // see the queue-entry comment
-                it = pix >> kPixBits; pix &= (1u << kPixBits) - 1u;
+                if (f.n_batch > 1) { it = pix >> kPixBits; pix &= (1u << kPixBits) - 1u; }      // a single iteration may use all 32 bits for the slot
                 rng.unpack((uint64_t)f2u(o4.w) | ((uint64_t)f2u(c4.w) << 32), ((uint64_t)(uint32_t)(f.iter0 + (float)it) << 1) | 1u);
                 const float t = u2f(h.x); const uint32_t id = h.y;
                 if (bounce == 0 && it + 1 == f.n_batch) hit_ids[pix] = id;

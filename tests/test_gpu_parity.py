@@ -417,3 +417,20 @@ def test_aabb_outline_debug_view(ctx, name, tracer):
     scene.params["camera"]["shouldRenderAABB"] = 0
     plain, _, _ = orc.render(scene, _params(scene, n)[0], w, h, flags=orc.TRAVERSE_FAST)
     assert np.array_equal(ctx.image().view(np.uint32), plain.view(np.uint32))
+
+
+def test_frame_with_more_than_2_26_pixel_slots():
+    """Maximum sizes: beyond 2^26 - 1 pixel slots the wavefront tracer cannot pack a batch index beside the slot, renders
+    one iteration per launch sequence and uses all 32 bits for the slot; the megakernel (checked against the oracle
+    above) is the reference at a size the oracle does not finish in seconds."""
+    w, h = 8192, 8200
+    assert w * h > (1 << 26)
+    scene = abi.builtin_scene("quads", w, h)
+    out = []
+    for tracer in (abi.TRACER_MEGAKERNEL, abi.TRACER_WAVEFRONT):
+        with abi.Context(0) as c:
+            img, ids, _ = _gpu_render(c, scene, w, h, 2, tracer=tracer)
+            out.append((img.view(np.uint32), ids))
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][0], out[1][0])
+    assert (out[0][0][..., 3].view(np.float32) == 2.0).all() and (out[0][1][h // 2:] != 0xFFFFFFFF).any()
