@@ -434,3 +434,57 @@ def test_frame_with_more_than_2_26_pixel_slots():
     assert np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][0], out[1][0])
     assert (out[0][0][..., 3].view(np.float32) == 2.0).all() and (out[0][1][h // 2:] != 0xFFFFFFFF).any()
+
+
+def _edge_scene(kind, w, h):
+    """Degenerate geometry the builders must survive: Morton collisions, zero-area and collinear triangles, huge offsets."""
+    base = abi.builtin_scene("book1", w, h)
+    rs = np.random.RandomState(7)
+    mats = base.materials[:8].copy()
+    if kind == "identical":            # every key equal: 600 copies of one triangle + 40 copies of one sphere
+        tris = np.zeros(600, abi.tri_dtype)
+        tris["v0"], tris["v1"], tris["v2"] = (-2, 0, -1), (2, 0.5, 0), (0, 3, 1)
+        tris["materialIndex"] = np.arange(600) % len(mats)
+        spheres = np.zeros(40, abi.sphere_dtype)
+        spheres["center"], spheres["radius"] = (0, 1, 0), 0.75
+        spheres["materialIndex"] = np.arange(40) % len(mats)
+    elif kind == "degenerate":         # points, needles and slivers among ordinary triangles
+        tris = np.zeros(900, abi.tri_dtype)
+        c = rs.uniform(-4, 4, (900, 3)).astype(np.float32) * np.float32([1, 0.3, 1]) + np.float32([0, 1, 0])
+        e = rs.uniform(-0.6, 0.6, (2, 900, 3)).astype(np.float32)
+        tris["v0"], tris["v1"], tris["v2"] = c, c + e[0], c + e[1]
+        tris["v1"][:100] = tris["v0"][:100]; tris["v2"][:100] = tris["v0"][:100]                   # points
+        tris["v2"][100:200] = tris["v0"][100:200] + 2 * (tris["v1"][100:200] - tris["v0"][100:200])  # collinear
+        tris["v2"][200:300] = tris["v1"][200:300]                                                    # two equal corners
+        tris["materialIndex"] = np.arange(900) % len(mats)
+        spheres = base.spheres[-5:].copy()
+        spheres["materialIndex"] = 0
+    else:                              # "far": ordinary geometry a million units from the origin
+        off = np.float32([1.0e6, -2.0e6, 5.0e5])
+        tris = np.zeros(500, abi.tri_dtype)
+        c = rs.uniform(-4, 4, (500, 3)).astype(np.float32) * np.float32([1, 0.3, 1]) + np.float32([0, 1, 0]) + off
+        e = rs.uniform(-0.8, 0.8, (2, 500, 3)).astype(np.float32)
+        tris["v0"], tris["v1"], tris["v2"] = c, c + e[0], c + e[1]
+        tris["materialIndex"] = np.arange(500) % len(mats)
+        spheres = np.zeros(1, abi.sphere_dtype)
+        spheres["center"], spheres["radius"] = off + np.float32([0, -2000, 0]), 2000
+    params = base.params.copy()
+    if kind == "far":
+        params["camera"]["position"] += off
+    return abi.HostScene(spheres=spheres, tris=tris, materials=mats, params=params, name="edge-" + kind)
+
+
+@pytest.mark.parametrize("bvh", [abi.BVH_LBVH, abi.BVH_SAH_REFINE, abi.BVH_LEAF_COLLAPSE, abi.BVH_LBVH | abi.BVH_WIDE, abi.BVH_SAH_REFINE | abi.BVH_WIDE],
+                         ids=["lbvh", "sah", "collapse", "lbvh-wide", "sah-wide"])
+@pytest.mark.parametrize("kind", ["identical", "degenerate", "far"])
+def test_degenerate_geometry_bit_exact(ctx, kind, bvh):
+    w, h = 80, 48
+    scene = _edge_scene(kind, w, h)
+    ref = None
+    for tracer in (abi.TRACER_MEGAKERNEL, abi.TRACER_WAVEFRONT):
+        img, ids, ps = _gpu_render(ctx, scene, w, h, 2, bvh=bvh, tracer=tracer)
+        if ref is None:
+            ref = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_BRUTE)
+        assert np.array_equal(ids, ref[1]), f"{(ids != ref[1]).sum()} primary-hit ID mismatches"
+        assert np.array_equal(img.view(np.uint32), ref[0].view(np.uint32))
+    assert (ref[1] != abi.ID_MISS).any()
