@@ -8,11 +8,11 @@
 //   tiers   Level-0 items are the primitives in Morton order.  The level-(l+1) items ("groups") are the maximal
 //           LBVH subtrees holding at most kGroup level-l items; a group is a contiguous run of items and, being
 //           an LBVH subtree, an aligned cell of the Morton grid.  Tiers are added until one group holds everything.
-//   groups  One 256-thread workgroup rebuilds one group entirely in LDS (boxes 24 KiB + index permutation):
-//             nodes with more than 64 items: all four waves, 16-bin SAH on three axes (LDS atomic min/max on
+//   groups  One 512-thread workgroup rebuilds one group entirely in LDS (boxes 24 KiB + index permutation):
+//             nodes with more than 64 items: all eight waves, 16-bin SAH on three axes (LDS atomic min/max on
 //               order-preserving keys), stable partition by ballot + prefix counts;
 //             nodes with at most 64 items: one wave per subtree, exact sweep SAH (every item's centroid is a
-//               candidate plane on every axis, item boxes broadcast with v_readlane), partition by ballot.
+//               candidate plane on every axis), all nodes of a level at once as segments of lanes (sah_wave_subtree).
 //           Level-0 groups may close a subtree of one kind as a multi-primitive leaf when the SAH says so.
 //   layout  A subtree over k items owns k - 1 consecutive 64-byte sibling pairs, itself first, then its left
 //           subtree, then its right one (depth-first order), so no allocation counter is needed and a group's
@@ -31,6 +31,8 @@
 namespace crt {
 
 constexpr uint32_t kGroup = 1024;       // items per group
+constexpr uint32_t kSahThreads = 512;   // eight waves share a group's small subtrees; two to three groups are resident per CU
+constexpr uint32_t kSahWaves = kSahThreads / 64;
 constexpr uint32_t kWaveNode = 64;      // nodes up to this size are built by one wave
 constexpr int kBins = 16;
 constexpr uint32_t kEntRoot = 1u << 23;
@@ -80,10 +82,9 @@ struct SahLds {
     uint16_t idx[kGroup], tmp[kGroup];
     uint8_t kind[kGroup];
     uint2 ent[2 * kGroup];           // work entries: stack of large nodes from the bottom, list of small subtrees from the top
-    uint2 wstack[4][kWaveNode + 2];
     uint32_t bins[3 * kBins * 7];    // per axis and bin: count, lo.xyz, hi.xyz (encoded)
     uint32_t red[12];                // centroid min, centroid max, box min, box max (encoded)
-    uint32_t wave_cnt[4];
+    uint32_t wave_cnt[kSahWaves];
     uint32_t top, n_small, cursor, best_axis, best_plane, best_nl;
 };
 
@@ -115,99 +116,115 @@ __device__ __forceinline__ void put_item(const SahGroupArgs &g, const SahLds &L,
 
 __device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
-__device__ __forceinline__ float lane_f(float v, uint32_t j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)j)); }
 
-// Sweep on one axis: this lane's candidate sends item j left when (c_j, j) <= (c_i, i).  Returns A_L n_L + A_R n_R.
-__device__ __forceinline__ float sweep_axis(uint32_t k, uint32_t lane, float ci, const float lo[3], const float hi[3]) {
-    float llo[3] = {kFInf, kFInf, kFInf}, lhi[3] = {-kFInf, -kFInf, -kFInf};
-    float rlo[3] = {kFInf, kFInf, kFInf}, rhi[3] = {-kFInf, -kFInf, -kFInf};
-    uint32_t nl = 0;
-    for (uint32_t j = 0; j < k; j++) {
-        const float cj = lane_f(ci, j);
-        const bool inl = cj < ci || (cj == ci && j <= lane);
+// Ascending bitonic sort of one 64-bit key per lane (keys are distinct: the lane is part of the key).
+__device__ __forceinline__ unsigned long long wave_sort(unsigned long long key, uint32_t lane) {
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const float bl = lane_f(lo[a], j), bh = lane_f(hi[a], j);
-            llo[a] = fminf(llo[a], inl ? bl : kFInf); lhi[a] = fmaxf(lhi[a], inl ? bh : -kFInf);
-            rlo[a] = fminf(rlo[a], inl ? kFInf : bl); rhi[a] = fmaxf(rhi[a], inl ? -kFInf : bh);
+    for (uint32_t k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            const unsigned long long other = __shfl_xor(key, (int)j);
+            const bool take_min = ((lane & j) == 0) == ((lane & k2) == 0);
+            key = (other < key) == take_min ? other : key;
         }
-        nl += inl ? 1u : 0u;
     }
-    if (nl >= k) return kFInf;
-    const float cost = half_area3(llo, lhi) * (float)nl + half_area3(rlo, rhi) * (float)(k - nl);
-    return cost < kFInf ? cost : kFInf;      // also turns a NaN into "invalid"
+    return key;
 }
 
-// One wave builds the whole subtree of a node with at most kWaveNode items.
-__device__ void sah_wave_subtree(const SahGroupArgs &g, SahLds &L, uint32_t group, uint32_t gs, uint32_t pair_base, uint2 e,
-                                 uint32_t wave, uint32_t lane) {
-    uint2 *stk = L.wstack[wave];
-    uint32_t sp = 0;
-    for (;;) {
-        const uint32_t ex = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x), y = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
-        const uint32_t a = ex & 0xFFFFu, b = ex >> 16, k = b - a, p = y & 0x7FFu;
-        if (k == 1) {
-            if (lane == 0) put_item(g, L, group, gs, pair_base, y, a);
-        } else {
-            const bool act = lane < k;
-            const uint32_t it = act ? L.idx[a + lane] : 0u;
-            float lo[3], hi[3], c[3], nlo[3], nhi[3];
+// One wave builds the whole subtree of a node with at most kWaveNode items, level by level.  Lane l holds the item at
+// position a + l of the permutation; the nodes of the current level are segments [s0, s1) of consecutive lanes and
+// every lane carries its segment's bookkeeping.  Per level and axis: sort the lanes by (segment, centroid), which
+// orders each segment in place; segmented prefix / suffix scans of the boxes then price every split of every segment
+// at once (exact sweep SAH: each item's centroid is a candidate plane).  The cheapest (axis, rank) of a segment is
+// found with a segmented min-scan, the segment is left in that axis's order and cut there.
+__device__ void sah_wave_subtree(const SahGroupArgs &g, SahLds &L, uint32_t group, uint32_t gs, uint32_t pair_base, uint2 e, uint32_t lane) {
+    const uint32_t ex = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
+    const uint32_t a = ex & 0xFFFFu, k = (ex >> 16) - a;
+    const bool act = lane < k;
+    uint32_t it = act ? L.idx[a + lane] : 0u;
+    float lo[3], hi[3];
 #pragma unroll
-            for (int ax = 0; ax < 3; ax++) {
-                lo[ax] = act ? L.box[ax][it] : kFInf; hi[ax] = act ? L.box[3 + ax][it] : -kFInf;
-                c[ax] = 0.5f * lo[ax] + 0.5f * hi[ax];
-                nlo[ax] = wave_min(lo[ax]); nhi[ax] = wave_max(hi[ax]);
-            }
-            const float area = half_area3(nlo, nhi);
-            // best split: minimum of A_L n_L + A_R n_R over every (axis, item) candidate
-            float best = kFInf; uint32_t best_ax = 0;
-            if (k == 2) { best = lane == 0 ? half_area3(lo, hi) + lane_f(half_area3(lo, hi), 1) : kFInf; }
-            else {
-                const float c0 = sweep_axis(k, lane, c[0], lo, hi);
-                const float c1 = sweep_axis(k, lane, c[1], lo, hi);
-                const float c2 = sweep_axis(k, lane, c[2], lo, hi);
-                best = c0; best_ax = 0;
-                if (c1 < best) { best = c1; best_ax = 1; }
-                if (c2 < best) { best = c2; best_ax = 2; }
-                if (!act) best = kFInf;
-            }
-            unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (best_ax * 64u + lane);
-            for (int o = 32; o > 0; o >>= 1) { unsigned long long other = __shfl_xor(key, o); key = other < key ? other : key; }
-            const uint32_t bl = (uint32_t)key & 63u, bax = ((uint32_t)key >> 6) & 3u;
-            const float split_cost = __uint_as_float((uint32_t)(key >> 32));
-            // multi-primitive leaf?  (level 0, one kind, at most max_leaf primitives, not more expensive than the split)
-            bool leaf = false;
-            const uint32_t kind = g.level0 ? (uint32_t)L.kind[it] : 0u;
-            if (g.level0 && k <= g.max_leaf) {
-                const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)kind, 0);
-                const bool same = __ballot(act && kind != k0) == 0ull;
-                leaf = same && g.c_isect * (float)k * area <= g.c_trav * area + g.c_isect * split_cost;
-            }
-            if (leaf) {
-                if (lane == 0) put_desc(g, group, pair_base, y, nlo, nhi, gs + a, (kind << 28) | k);
-            } else {
-                const float cme = bax == 0 ? c[0] : bax == 1 ? c[1] : c[2];
-                const float cb = lane_f(cme, bl);
-                bool inl = k == 2 ? lane == 0 : act && (cme < cb || (cme == cb && lane <= bl));
-                unsigned long long ml = __ballot(inl);
-                if (ml == 0ull || (uint32_t)__popcll(ml) >= k) { inl = lane < k / 2u; ml = __ballot(inl); }     // no finite candidate: halve the order
-                const unsigned long long mr = __ballot(act && !inl), lt = (1ull << lane) - 1ull;
-                const uint32_t nl = (uint32_t)__popcll(ml);
-                if (act) L.idx[a + (inl ? (uint32_t)__popcll(ml & lt) : nl + (uint32_t)__popcll(mr & lt))] = (uint16_t)it;
-                __threadfence_block();
-                if (lane == 0) put_desc(g, group, pair_base, y, nlo, nhi, pair_base + p, 0u);
-                const uint2 le = make_ent(a, a + nl, p + 1u, p, 0u), re = make_ent(a + nl, b, p + nl, p, 1u);
-                if (b - a - nl == 1u) { if (lane == 0) put_item(g, L, group, gs, pair_base, re.y, a + nl); }
-                else { stk[sp] = re; sp++; }
-                if (nl == 1u) { if (lane == 0) put_item(g, L, group, gs, pair_base, le.y, a); }
-                else { stk[sp] = le; sp++; }
-                __threadfence_block();
-            }
+    for (int ax = 0; ax < 3; ax++) { lo[ax] = act ? L.box[ax][it] : kFInf; hi[ax] = act ? L.box[3 + ax][it] : -kFInf; }
+    uint32_t kind = (g.level0 && act) ? (uint32_t)L.kind[it] : 0u;
+    uint32_t s0 = act ? 0u : lane, s1 = act ? k : lane + 1u;         // lanes past k: closed one-lane segments that stay put
+    uint32_t y = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);  // p | pp << 11 | side << 22 | root << 23 of my segment
+    bool open = act;
+    for (;;) {
+        if (open && s1 - s0 == 1u) {                                  // a single item: its descriptor, done
+            uint32_t link, count;
+            if (g.level0) { link = gs + a + lane; count = (kind << 28) | 1u; }       // link = final position, patched to the kind's slot later
+            else { link = __float_as_uint(g.desc_in[2 * (size_t)(gs + it)].w); count = __float_as_uint(g.desc_in[2 * (size_t)(gs + it) + 1].w); }
+            put_desc(g, group, pair_base, y, lo, hi, link, count);
+            open = false;
         }
-        if (sp == 0) break;
-        sp--;
-        e = stk[sp];
+        if (__ballot(open) == 0ull) break;
+        const uint32_t len = s1 - s0;
+        float best = kFInf, nlo[3], nhi[3];
+        uint32_t best_ax = 0, src[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) {
+            const float c = 0.5f * lo[ax] + 0.5f * hi[ax];
+            const unsigned long long key = wave_sort(((unsigned long long)s0 << 40) | ((unsigned long long)enc_f(c) << 8) | lane, lane);
+            src[ax] = (uint32_t)key & 63u;
+            float llo[3], lhi[3], rlo[3], rhi[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) { llo[d] = rlo[d] = __shfl(lo[d], (int)src[ax]); lhi[d] = rhi[d] = __shfl(hi[d], (int)src[ax]); }
+#pragma unroll
+            for (uint32_t off = 1; off < 64; off <<= 1) {             // inclusive scans inside the segment: left box up to me, right box from me
+                const bool tl = lane >= s0 + off, tr = lane + off < s1;
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const float a0 = __shfl_up(llo[d], off), a1 = __shfl_up(lhi[d], off), b0 = __shfl_down(rlo[d], off), b1 = __shfl_down(rhi[d], off);
+                    llo[d] = fminf(llo[d], tl ? a0 : kFInf); lhi[d] = fmaxf(lhi[d], tl ? a1 : -kFInf);
+                    rlo[d] = fminf(rlo[d], tr ? b0 : kFInf); rhi[d] = fmaxf(rhi[d], tr ? b1 : -kFInf);
+                }
+            }
+            if (ax == 0) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) { nlo[d] = __shfl(rlo[d], (int)s0); nhi[d] = __shfl(rhi[d], (int)s0); }      // the segment's box
+            }
+#pragma unroll
+            for (int d = 0; d < 3; d++) { rlo[d] = __shfl_down(rlo[d], 1); rhi[d] = __shfl_down(rhi[d], 1); }             // right box = everything after me
+            const uint32_t nl = lane - s0 + 1u, nr = s1 - lane - 1u;
+            float cost = half_area3(llo, lhi) * (float)nl + half_area3(rlo, rhi) * (float)nr;
+            cost = (open && lane + 1u < s1 && cost < kFInf) ? cost : kFInf;      // also turns a NaN into "invalid"
+            if (cost < best) { best = cost; best_ax = (uint32_t)ax; }
+        }
+        // cheapest candidate of the segment: inclusive min-scan, read at the segment's last lane
+        unsigned long long bk = ((unsigned long long)__float_as_uint(best) << 32) | (best_ax << 8) | lane;
+#pragma unroll
+        for (uint32_t off = 1; off < 64; off <<= 1) { const unsigned long long o = __shfl_up(bk, off); if (lane >= s0 + off && o < bk) bk = o; }
+        bk = __shfl(bk, (int)(s1 - 1u));
+        const float split_cost = __uint_as_float((uint32_t)(bk >> 32));
+        const bool valid = split_cost < kFInf;
+        const uint32_t bax = ((uint32_t)bk >> 8) & 3u;
+        uint32_t nl = valid ? ((uint32_t)bk & 63u) - s0 + 1u : len / 2u;         // no finite candidate: halve the current order
+        // multi-primitive leaf?  (level 0, one kind, at most max_leaf primitives, not more expensive than the split)
+        bool leaf = false;
+        const uint32_t kind0 = (uint32_t)__shfl((int)kind, (int)s0);
+        const unsigned long long mism = __ballot(open && kind != kind0);
+        if (g.level0 && open && len <= g.max_leaf) {
+            const unsigned long long seg = (len >= 64u ? ~0ull : (1ull << len) - 1ull) << s0;
+            const float area = half_area3(nlo, nhi);
+            leaf = (mism & seg) == 0ull && g.c_isect * (float)len * area <= g.c_trav * area + g.c_isect * split_cost;
+        }
+        const uint32_t p = y & 0x7FFu;
+        if (open && lane == s0) {
+            if (leaf) put_desc(g, group, pair_base, y, nlo, nhi, gs + a + s0, (kind << 28) | len);
+            else put_desc(g, group, pair_base, y, nlo, nhi, pair_base + p, 0u);
+        }
+        if (leaf) open = false;
+        // leave every split segment in its axis's order, then cut it
+        const uint32_t from = (open && valid) ? (bax == 0 ? src[0] : bax == 1 ? src[1] : src[2]) : lane;
+        it = (uint32_t)__shfl((int)it, (int)from); kind = (uint32_t)__shfl((int)kind, (int)from);
+#pragma unroll
+        for (int d = 0; d < 3; d++) { lo[d] = __shfl(lo[d], (int)from); hi[d] = __shfl(hi[d], (int)from); }
+        if (open) {
+            if (lane < s0 + nl) { s1 = s0 + nl; y = (p + 1u) | (p << 11); }
+            else { s0 = s0 + nl; y = (p + nl) | (p << 11) | (1u << 22); }
+        }
     }
+    if (act) L.idx[a + lane] = (uint16_t)it;
 }
 
 __device__ __forceinline__ int bin_of(float c, float cmin, float scale) {
@@ -215,13 +232,13 @@ __device__ __forceinline__ int bin_of(float c, float cmin, float scale) {
     return b < 0 ? 0 : b > kBins - 1 ? kBins - 1 : b;
 }
 
-__global__ __launch_bounds__(256) void k_sah_group(SahGroupArgs g) {
+__global__ __launch_bounds__(kSahThreads) void k_sah_group(SahGroupArgs g) {
     __shared__ SahLds L;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t group = blockIdx.x;
     const uint32_t gs = g.starts[group], ge = group + 1 < g.n_groups ? g.starts[group + 1] : g.n_items, m = ge - gs;
     const uint32_t pair_base = g.pair_base + gs - group;
-    for (uint32_t i = tid; i < m; i += 256) {
+    for (uint32_t i = tid; i < m; i += kSahThreads) {
         float4 lo, hi;
         if (g.level0) {
             const uint32_t prim = g.vals[gs + i];
@@ -244,11 +261,11 @@ __global__ __launch_bounds__(256) void k_sah_group(SahGroupArgs g) {
         const uint2 e = L.ent[top - 1];
         const uint32_t a = e.x & 0xFFFFu, b = e.x >> 16, k = b - a, p = e.y & 0x7FFu;
         if (tid < 12) L.red[tid] = (tid % 6) < 3 ? 0xFFFFFFFFu : 0u;
-        for (uint32_t t = tid; t < 3 * kBins * 7; t += 256) { const uint32_t f = t % 7; L.bins[t] = f == 0 ? 0u : f <= 3 ? 0xFFFFFFFFu : 0u; }
+        for (uint32_t t = tid; t < 3 * kBins * 7; t += kSahThreads) { const uint32_t f = t % 7; L.bins[t] = f == 0 ? 0u : f <= 3 ? 0xFFFFFFFFu : 0u; }
         __syncthreads();
         {   // bounds of the centroids and of the node
             float cmn[3] = {kFInf, kFInf, kFInf}, cmx[3] = {-kFInf, -kFInf, -kFInf}, bmn[3] = {kFInf, kFInf, kFInf}, bmx[3] = {-kFInf, -kFInf, -kFInf};
-            for (uint32_t i = a + tid; i < b; i += 256) {
+            for (uint32_t i = a + tid; i < b; i += kSahThreads) {
                 const uint32_t it = L.idx[i];
 #pragma unroll
                 for (int ax = 0; ax < 3; ax++) {
@@ -273,7 +290,7 @@ __global__ __launch_bounds__(256) void k_sah_group(SahGroupArgs g) {
             const float ext = dec_f(L.red[3 + ax]) - cmin[ax];
             scale[ax] = ext > 0.0f ? (float)kBins / ext : 0.0f;
         }
-        for (uint32_t i = a + tid; i < b; i += 256) {
+        for (uint32_t i = a + tid; i < b; i += kSahThreads) {
             const uint32_t it = L.idx[i];
             uint32_t elo[3], ehi[3]; float c[3];
 #pragma unroll
@@ -319,7 +336,7 @@ __global__ __launch_bounds__(256) void k_sah_group(SahGroupArgs g) {
         if (bax < 3u) {      // stable partition of idx[a, b) (no valid plane: all centroids coincide, split the order in half)
             const float cm = bax == 0 ? cmin[0] : bax == 1 ? cmin[1] : cmin[2], sc = bax == 0 ? scale[0] : bax == 1 ? scale[1] : scale[2];
             uint32_t left_before = 0;
-            for (uint32_t base = a; base < b; base += 256) {
+            for (uint32_t base = a; base < b; base += kSahThreads) {
                 const uint32_t i = base + tid;
                 const bool valid = i < b;
                 const uint32_t it = valid ? L.idx[i] : 0u;
@@ -329,13 +346,13 @@ __global__ __launch_bounds__(256) void k_sah_group(SahGroupArgs g) {
                 if (lane == 0) L.wave_cnt[wave] = (uint32_t)__popcll(ml);
                 __syncthreads();
                 uint32_t before = left_before, chunk = 0;
-                for (uint32_t w = 0; w < 4; w++) { const uint32_t cw = L.wave_cnt[w]; if (w < wave) before += cw; chunk += cw; }
+                for (uint32_t w = 0; w < kSahWaves; w++) { const uint32_t cw = L.wave_cnt[w]; if (w < wave) before += cw; chunk += cw; }
                 const uint32_t lrank = before + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull));
                 if (valid) L.tmp[left ? a + lrank : a + nl + ((i - a) - lrank)] = (uint16_t)it;
                 left_before += chunk;
                 __syncthreads();
             }
-            for (uint32_t i = a + tid; i < b; i += 256) L.idx[i] = L.tmp[i];
+            for (uint32_t i = a + tid; i < b; i += kSahThreads) L.idx[i] = L.tmp[i];
         }
         __syncthreads();
         if (tid == 0) {
@@ -357,10 +374,10 @@ __global__ __launch_bounds__(256) void k_sah_group(SahGroupArgs g) {
         if (lane == 0) i = atomicAdd(&L.cursor, 1u);
         i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
         if (i >= n_small) break;
-        sah_wave_subtree(g, L, group, gs, pair_base, L.ent[2 * kGroup - 1 - i], wave, lane);
+        sah_wave_subtree(g, L, group, gs, pair_base, L.ent[2 * kGroup - 1 - i], lane);
     }
     __syncthreads();
-    if (g.level0) for (uint32_t i = tid; i < m; i += 256) g.perm[gs + i] = g.vals[gs + L.idx[i]];
+    if (g.level0) for (uint32_t i = tid; i < m; i += kSahThreads) g.perm[gs + i] = g.vals[gs + L.idx[i]];
 }
 
 // Leaf links were written as final sorted positions; turn them into slots of the kind's packed array.
@@ -437,7 +454,7 @@ bool build_sah(hipStream_t stream, const BuildInput &in, BuildState &st, const u
         g.desc_out = t + 1 == tiers.size() ? nullptr : desc + 2 * tiers[t].starts_off;
         g.pairs = (float4 *)st.pairs.ptr; g.perm = (uint32_t *)st.perm.ptr;
         g.max_leaf = st.max_leaf < 1u ? 1u : st.max_leaf > 8u ? 8u : st.max_leaf; g.c_isect = st.c_isect; g.c_trav = st.c_trav;
-        hipLaunchKernelGGL(k_sah_group, dim3(g.n_groups), dim3(256), 0, stream, g);
+        hipLaunchKernelGGL(k_sah_group, dim3(g.n_groups), dim3(kSahThreads), 0, stream, g);
     }
     HIP_TRY(hipGetLastError());
     st.sah_tiers = (uint32_t)tiers.size();
