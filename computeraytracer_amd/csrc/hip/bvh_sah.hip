@@ -8,8 +8,8 @@
 //   tiers   Level-0 items are the primitives in Morton order.  The level-(l+1) items ("groups") are the maximal
 //           LBVH subtrees holding at most kGroup level-l items; a group is a contiguous run of items and, being
 //           an LBVH subtree, an aligned cell of the Morton grid.  Tiers are added until one group holds everything.
-//   groups  One 512-thread workgroup rebuilds one group entirely in LDS (boxes 24 KiB + index permutation):
-//             nodes with more than 64 items: all eight waves, 16-bin SAH on three axes (LDS atomic min/max on
+//   groups  One 256-thread workgroup rebuilds one group entirely in LDS (boxes + index permutation):
+//             nodes with more than 64 items: all four waves, 16-bin SAH on three axes (LDS atomic min/max on
 //               order-preserving keys), stable partition by ballot + prefix counts;
 //             nodes with at most 64 items: one wave per subtree, exact sweep SAH (every item's centroid is a
 //               candidate plane on every axis), all nodes of a level at once as segments of lanes (sah_wave_subtree).
@@ -30,8 +30,14 @@
 
 namespace crt {
 
-constexpr uint32_t kGroup = 1024;       // items per group
-constexpr uint32_t kSahThreads = 512;   // eight waves share a group's small subtrees; two to three groups are resident per CU
+#ifndef CRT_SAH_GROUP
+#define CRT_SAH_GROUP 256
+#endif
+constexpr uint32_t kGroup = CRT_SAH_GROUP;       // items per group (A/B on MI355X: 256 builds fastest, trace speed within noise of 1024)
+#ifndef CRT_SAH_THREADS
+#define CRT_SAH_THREADS 256
+#endif
+constexpr uint32_t kSahThreads = CRT_SAH_THREADS;   // the waves of a group share its small subtrees; several groups are resident per CU
 constexpr uint32_t kSahWaves = kSahThreads / 64;
 constexpr uint32_t kWaveNode = 64;      // nodes up to this size are built by one wave
 constexpr int kBins = 16;
