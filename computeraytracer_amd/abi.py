@@ -31,6 +31,9 @@ tri_dtype = np.dtype([("v0", "<f4", 3), ("pad0", "<f4"), ("v1", "<f4", 3), ("pad
                       ("materialIndex", "<u4")])
 material_dtype = np.dtype([("albedo", "<f4", 3), ("fuzziness", "<f4"), ("pad0", "<f4", 3), ("type", "<u4"),
                            ("pad1", "<f4", 3), ("textureIndex", "<u4")])
+ray_dtype = np.dtype([("origin", "<f4", 3), ("t_max", "<f4"), ("direction", "<f4", 3), ("pad", "<u4")])
+ray_hit_dtype = np.dtype([("t", "<f4"), ("id", "<u4")])
+QUERY_CLOSEST, QUERY_ANY = 0, 1
 camera_dtype = np.dtype([("position", "<f4", 3), ("shouldRenderAABB", "<u4"), ("backward", "<f4", 3), ("lensRadius", "<f4"),
                          ("right", "<f4", 3), ("focusDistance", "<f4"), ("up", "<f4", 3), ("iteration", "<f4"),
                          ("horizontal", "<f4", 3), ("seed", "<f4"), ("vertical", "<f4", 3), ("pad", "<f4")])
@@ -90,6 +93,7 @@ def _load():
         "crt_tris_animate": (i32, [vp, f32, f32]),
         "crt_dispatch": (i32, [vp, vp]),
         "crt_render": (i32, [vp, vp, u32, u32, vp]),
+        "crt_rays_query": (i32, [vp, vp, u32, u32, vp]),
         "crt_sync": (i32, [vp]),
         "crt_image_read": (i32, [vp, vp, C.c_size_t]),
         "crt_hit_ids_read": (i32, [vp, vp, C.c_size_t]),
@@ -311,6 +315,13 @@ class Context:
         p = np.ascontiguousarray(params, dtype=params_dtype)
         s = np.ascontiguousarray(seeds, dtype=np.float32)
         self._check(lib.crt_render(self._h, _ptr(p), first_iteration, len(s), _ptr(s)), "crt_render")
+
+    def rays_query(self, rays, mode=QUERY_CLOSEST):
+        """crt_rays_query on a numpy array of ray_dtype; returns an array of ray_hit_dtype."""
+        r = np.ascontiguousarray(rays, dtype=ray_dtype)
+        out = np.zeros(len(r), dtype=ray_hit_dtype)
+        self._check(lib.crt_rays_query(self._h, _ptr(r) if len(r) else None, len(r), mode, _ptr(out) if len(r) else None), "crt_rays_query")
+        return out
 
     def sync(self):
         self._check(lib.crt_sync(self._h), "crt_sync")

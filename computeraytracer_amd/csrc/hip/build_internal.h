@@ -78,7 +78,7 @@ struct DeviceStats {
 
 struct WavefrontState {
     uint32_t capacity = 0;           // paths the queues can hold
-    DeviceBuffer ray_o[2], ray_d[2], thr[2], hit, counters, pass;
+    DeviceBuffer ray_o[2], ray_d[2], thr[2], hit, counters, pass, query_rays;
     bool time_kernels = false;
     std::vector<hipEvent_t> ev;      // start/stop pairs around extend launches
     size_t ev_used = 0;
@@ -91,6 +91,9 @@ bool launch_megakernel(hipStream_t stream, const DeviceSceneHost &sc, const Fram
 bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sc, const FrameSetup &fs, const crt_scene_params &params,
                       uint32_t n_batch, const float *seeds, WavefrontState &wf, float *accum, uint32_t accum_pixels,
                       uint32_t *hit_ids, DeviceStats *stats, std::string &err);
+// crt_rays_query: answers n_rays caller rays (host or device memory) with one k_wf_extend launch; synchronous.
+bool launch_ray_query(hipStream_t stream, const DeviceSceneHost &sc, const FrameSetup &fs, WavefrontState &wf, const crt_ray *rays,
+                      uint32_t n_rays, uint32_t mode, crt_ray_hit *hits, DeviceStats *stats, std::string &err);
 void free_wavefront(WavefrontState &wf);
 
 }  // namespace crt

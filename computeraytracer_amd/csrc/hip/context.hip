@@ -332,6 +332,21 @@ int crt_render(crt_context *ctx, const crt_scene_params *params, uint32_t first_
     return rc;
 }
 
+int crt_rays_query(crt_context *ctx, const crt_ray *rays, uint32_t n_rays, uint32_t mode, crt_ray_hit *hits) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!ctx->have_scene) return fail(ctx, CRT_ERR_INVALID, "crt_rays_query: crt_scene_upload has not been called");
+    if (!ctx->have_bvh) return fail(ctx, CRT_ERR_INVALID, "crt_rays_query: crt_bvh_build has not been called for the current scene");
+    if (mode > CRT_QUERY_ANY) return fail(ctx, CRT_ERR_INVALID, "crt_rays_query: unknown mode");
+    if (n_rays && (!rays || !hits)) return fail(ctx, CRT_ERR_INVALID, "crt_rays_query: null rays/hits");
+    if ((rc = finish_timing(ctx))) return rc;
+    std::string err;
+    FrameSetup fs{};
+    fs.small_stack = (ctx->configured && (ctx->cfg.flags & CRT_FLAG_DEBUG_SMALL_STACK)) ? 1u : 0u;
+    if (!launch_ray_query(ctx->stream, scene_view(ctx), fs, ctx->wf, rays, n_rays, mode, hits, (DeviceStats *)ctx->stats.ptr, err))
+        return fail(ctx, CRT_ERR_HIP, "crt_rays_query: " + err);
+    return CRT_OK;
+}
+
 int crt_sync(crt_context *ctx) {
     int rc = bind(ctx); if (rc) return rc;
     CTX_HIP(hipStreamSynchronize(ctx->stream));

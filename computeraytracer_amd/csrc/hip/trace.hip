@@ -286,7 +286,9 @@ static_assert(kLdsStack * 4 == kWideLds * 8, "both stack layouts use the same LD
 #ifndef CRT_EXTEND_WAVES
 #define CRT_EXTEND_WAVES 6
 #endif
-template <bool COUNT, bool WIDE, bool SPILL>
+// QUERY (crt_rays_query): 0 = path segments; 1 = caller's rays, closest hit in (t_near, t_max] (t_max rides in ray_o.w);
+// 2 = same interval, any hit: a lane stops at the first primitive it finds.
+template <bool COUNT, bool WIDE, bool SPILL, int QUERY = 0>
 __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene sc, WfQueues q, uint32_t bounce, unsigned long long dead, DeviceStats *stats) {
     __shared__ uint2 s_stack[kWideLds * 256];
     __shared__ uint8_t s_order[WIDE ? kWideOrderBytes : 4];
@@ -356,7 +358,11 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
                     slot = pool_base + i;
                     float4 o4 = ro[slot], d4 = rd[slot];
                     if (f2u(d4.w) == kDeadPixel) q.hit[slot] = make_uint2(f2u(kInf), kIdMiss);
-                    else { lt.begin(mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z)); busy = true; }
+                    else {
+                        lt.begin(mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z));
+                        if (QUERY) { lt.tr.best_t = o4.w; lt.tr.tfar = o4.w * 1.000004f; }
+                        busy = true;
+                    }
                 }
                 pool_next = min(pool_end, pool_next + (uint32_t)__popcll(idle));
             }
@@ -379,6 +385,7 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
             if (COUNT) { c_inner++; c_inner_lanes += (uint32_t)__popcll(__ballot(busy && !at_leaf)); }
             if (busy && !at_leaf) more = lt.template inner<COUNT>(sc, s_order, stack, spill, lds_depth, cnt);
         }
+        if (QUERY == 2 && busy && lt.tr.best_id != kIdMiss) more = false;
         if (!more) {
             q.hit[slot] = make_uint2(f2u(lt.tr.best_t), lt.tr.best_id);
             busy = false;
@@ -583,9 +590,81 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     return true;
 }
 
+// ---- ray queries (crt_rays_query) ----------------------------------------------------------------------------
+// The caller's rays become bounce-0 queue entries (slot = ray index; the sub-queues are contiguous runs of slots) and
+// one k_wf_extend launch answers them into q.hit.
+__global__ void k_query_init(WfQueues q, uint32_t n_rays) {
+    for (uint32_t i = threadIdx.x; i < kShards; i += blockDim.x) {
+        const unsigned long long first = (unsigned long long)i * q.shard_cap;
+        q.counts[i * kCtrStride] = (i < q.n_shards && first < n_rays) ? (uint32_t)min((unsigned long long)q.shard_cap, n_rays - first) : 0u;
+        q.cursors[i * kCtrStride] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_query_pack(WfQueues q, const crt_ray *rays, uint32_t n_rays) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays) return;
+    const float4 *r = (const float4 *)(rays + i);
+    const float4 a = r[0], b = r[1];
+    q.ray_o[0][i] = a;                                            // origin, t_max
+    q.ray_d[0][i] = make_float4(b.x, b.y, b.z, u2f(i));           // direction, any value but kDeadPixel
+}
+
+bool launch_ray_query(hipStream_t stream, const DeviceSceneHost &sch, const FrameSetup &fs, WavefrontState &wf, const crt_ray *rays,
+                      uint32_t n_rays, uint32_t mode, crt_ray_hit *hits, DeviceStats *stats, std::string &err) {
+    static_assert(sizeof(crt_ray) == 32 && sizeof(crt_ray_hit) == 8, "crt_ray / crt_ray_hit layout");
+    if (n_rays == 0) return true;
+    if (n_rays == 0xFFFFFFFFu) { err = "at most 2^32 - 2 rays per query"; return false; }
+    if (sch.n_pairs + 1 >= kMaxLeafLink) { err = "wavefront tracer supports at most 2^26 primitives"; return false; }
+    DeviceScene sc = to_device_scene(sch);
+    WfQueues q;
+    const uint32_t n_tiles = (n_rays + 63) / 64;
+    q.n_shards = n_tiles >= 64 * 16 ? 64 : 1;                    // sub-queues only pay once every wave can have its own chunks
+    q.precheck = 1; q.refill = kRefillLanes; q.leaf_lanes = 16;
+    q.tiles_per_shard = (n_tiles + q.n_shards - 1) / q.n_shards;
+    q.shard_cap = q.tiles_per_shard * 64;
+    const size_t cap = (size_t)q.shard_cap * q.n_shards;
+    if (cap >= 0xFFFFFFFFull) { err = "too many rays for one query"; return false; }
+    if (wf.capacity < cap) {
+        for (int k = 0; k < 2; k++) {
+            if (!ensure_dev(wf.ray_o[k], cap * 16, err) || !ensure_dev(wf.ray_d[k], cap * 16, err) || !ensure_dev(wf.thr[k], cap * 16, err)) return false;
+        }
+        if (!ensure_dev(wf.hit, cap * 8, err) || !ensure_dev(wf.counters, (size_t)(2 * kMaxBounces + 1) * kShards * kCtrStride * 4, err)) return false;
+        wf.capacity = (uint32_t)cap;
+    }
+    if (!ensure_dev(wf.query_rays, (size_t)n_rays * sizeof(crt_ray), err)) return false;
+    HIP_TRY(hipMemcpyAsync(wf.query_rays.ptr, rays, (size_t)n_rays * sizeof(crt_ray), hipMemcpyDefault, stream));     // host or device memory
+    for (int k = 0; k < 2; k++) { q.ray_o[k] = (float4 *)wf.ray_o[k].ptr; q.ray_d[k] = (float4 *)wf.ray_d[k].ptr; q.thr[k] = (float4 *)wf.thr[k].ptr; }
+    q.hit = (uint2 *)wf.hit.ptr;
+    q.counts = (uint32_t *)wf.counters.ptr;
+    q.cursors = q.counts + (kMaxBounces + 1) * kShards * kCtrStride;
+    q.lds_depth = fs.small_stack ? 1u : (sc.wide ? (uint32_t)kWideLds : (uint32_t)kLdsStack);
+    uint32_t nb = (uint32_t)((cap + 255) / 256);
+    const uint32_t resident = 256u * CRT_EXTEND_WAVES;
+    nb = nb < resident ? ((nb + 15) / 16) * 16 : resident;
+    const dim3 block(256), pgrid(nb);
+    hipLaunchKernelGGL(k_query_init, dim3(1), dim3(256), 0, stream, q, n_rays);
+    hipLaunchKernelGGL(k_query_pack, dim3((n_rays + 255) / 256), block, 0, stream, q, (const crt_ray *)wf.query_rays.ptr, n_rays);
+    const bool any = mode == CRT_QUERY_ANY;
+    if (sc.wide && sch.wide_levels <= q.lds_depth + 1u) {
+        if (any) hipLaunchKernelGGL((k_wf_extend<false, true, false, 2>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
+        else hipLaunchKernelGGL((k_wf_extend<false, true, false, 1>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
+    } else if (sc.wide) {
+        if (any) hipLaunchKernelGGL((k_wf_extend<false, true, true, 2>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
+        else hipLaunchKernelGGL((k_wf_extend<false, true, true, 1>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
+    } else {
+        if (any) hipLaunchKernelGGL((k_wf_extend<false, false, true, 2>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
+        else hipLaunchKernelGGL((k_wf_extend<false, false, true, 1>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(hits, wf.hit.ptr, (size_t)n_rays * sizeof(crt_ray_hit), hipMemcpyDefault, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return true;
+}
+
 void free_wavefront(WavefrontState &wf) {
     DeviceBuffer *all[] = {&wf.ray_o[0], &wf.ray_o[1], &wf.ray_d[0], &wf.ray_d[1], &wf.thr[0], &wf.thr[1],
-                           &wf.hit, &wf.counters, &wf.pass};
+                           &wf.hit, &wf.counters, &wf.pass, &wf.query_rays};
     for (DeviceBuffer *b : all) if (b->ptr) { hipError_t e = hipFree(b->ptr); (void)e; b->ptr = nullptr; b->bytes = 0; }
     for (hipEvent_t e : wf.ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     wf.ev.clear(); wf.ev_used = 0;

@@ -87,6 +87,14 @@ int crt_dispatch(crt_context *ctx, const crt_scene_params *params);
 int crt_render(crt_context *ctx, const crt_scene_params *params, uint32_t first_iteration,
                uint32_t n_iterations, const float *seeds);
 
+/* Ray queries against the current scene and BVH: closest hit or any hit ("shadow ray") for n_rays caller-supplied
+ * rays, the same hit_world the path tracer runs (compute.comp:326-361: same intersection arithmetic, same interval
+ * rule, same tie-break), answered by one launch of the tracer's persistent traversal kernel.  The reference has no
+ * such entry point (its shader is hit_world's only caller); it serves engine-side picking, visibility and
+ * light-sampling passes.  rays / hits may be host or device memory.  Synchronous.  Uses the wavefront tracer's
+ * queues whatever crt_config.tracer says, so do not overlap it with a render on the same context. */
+int crt_rays_query(crt_context *ctx, const crt_ray *rays, uint32_t n_rays, uint32_t mode, crt_ray_hit *hits);
+
 /* Replaces waitForFences(renderFence) (vk_engine.cpp:1377). */
 int crt_sync(crt_context *ctx);
 

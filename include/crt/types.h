@@ -124,6 +124,22 @@ typedef struct crt_scene_desc {
 #define CRT_ID_MISS        0xFFFFFFFFu
 #define CRT_MAKE_ID(kind, index) (((uint32_t)(kind) << 30) | (uint32_t)(index))
 
+/* crt_rays_query: hit_world (compute.comp:326-361) for caller-supplied rays.  Both structs are plain FP32/u32. */
+typedef struct crt_ray {
+    float origin[3];
+    float t_max;         /* hits are searched in (0.001, t_max]; INFINITY for an unbounded ray */
+    float direction[3];  /* unit length, like every ray of the shader (hit_sphere, compute.comp:229-239, relies on it) */
+    uint32_t pad;
+} crt_ray;               /* 32 B */
+typedef struct crt_ray_hit {
+    float t;             /* distance of the hit; only meaningful when id != CRT_ID_MISS */
+    uint32_t id;         /* primitive ID or CRT_ID_MISS */
+} crt_ray_hit;
+enum {
+    CRT_QUERY_CLOSEST = 0,  /* the closest hit, lowest ID on exactly equal distances (what ray_color's hit_world returns) */
+    CRT_QUERY_ANY = 1       /* shadow rays: id != CRT_ID_MISS iff SOME primitive is hit in the interval; which one is unspecified */
+};
+
 /* crt_config.rng_mode */
 enum {
     CRT_RNG_REF = 0,   /* the shader's float-seeded integer hash, compute.comp:116-139 (bit-exact) */

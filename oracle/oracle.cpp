@@ -622,9 +622,9 @@ inline bool slab_double(const double lo[3], const double hi[3], const Ray &ray, 
 }
 
 // compute.comp:326-361 (ORC_TRAVERSE_REF) and its order-independent variants.
-bool hit_world(const World &w, const Ray &ray, Hit &rec, Counters &cnt) {
+bool hit_world(const World &w, const Ray &ray, Hit &rec, Counters &cnt, float tmax = INF_F) {
     cnt.rays++;
-    rec.t = INF_F; rec.id = ID_MISS;
+    rec.t = tmax; rec.id = ID_MISS;
     if (w.traverse == ORC_TRAVERSE_BRUTE) {
         for (uint32_t id : w.all_ids) test_prim(w, ray, id, rec, cnt);
     } else if (w.traverse == ORC_TRAVERSE_FAST) {
@@ -950,6 +950,28 @@ int orc_render(const orc_scene *scene, const orc_world_desc *world, const orc_bu
     }
     if (counters) { counters->rays = total.rays; counters->node_visits = total.node_visits; counters->prim_tests = total.prim_tests;
                     counters->paths = total.paths; counters->bounces = total.bounces; }
+    return 0;
+}
+
+/* hit_world for caller-supplied rays (the checker of crt_rays_query): rays = n x {origin[3], t_max, direction[3], pad},
+ * out = n x {t, id}; hits are searched in (T_NEAR, t_max].  BRUTE / FAST traversal only (canonical tie-break). */
+int orc_hit_rays(const orc_scene *scene, int flags, const float *rays, uint32_t n, int threads, void *out) {
+    World w;
+    world_init(w, to_scene(scene), flags);
+    if (w.traverse != ORC_TRAVERSE_BRUTE && w.traverse != ORC_TRAVERSE_FAST) return -1;
+    struct RayHit { float t; uint32_t id; };
+    RayHit *o = (RayHit *)out;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < (int64_t)n; i++) {
+        const float *r = rays + 8 * i;
+        Ray ray{v3(r), v3(r + 4)};
+        Hit rec{}; Counters c{};
+        hit_world(w, ray, rec, c, r[3]);
+        o[i].t = rec.t; o[i].id = rec.id;
+    }
     return 0;
 }
 

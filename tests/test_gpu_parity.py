@@ -488,3 +488,86 @@ def test_degenerate_geometry_bit_exact(ctx, kind, bvh):
         assert np.array_equal(ids, ref[1]), f"{(ids != ref[1]).sum()} primary-hit ID mismatches"
         assert np.array_equal(img.view(np.uint32), ref[0].view(np.uint32))
     assert (ref[1] != abi.ID_MISS).any()
+
+
+def _query_rays(scene, n, seed):
+    """Rays from the camera towards (jittered) primitive centres, rays between such points (shadow-ray shaped, t_max a multiple of their distance) and axis-parallel rays."""
+    rs = np.random.RandomState(seed)
+    centres = np.concatenate([scene.spheres["center"], scene.quads["corner"] + 0.5 * (scene.quads["u"] + scene.quads["v"]),
+                              (scene.tris["v0"] + scene.tris["v1"] + scene.tris["v2"]) / 3.0]).astype(np.float32)
+    extent = np.float32(0.05) * (centres.max(axis=0) - centres.min(axis=0) + np.float32(0.1))
+
+    def points(k):
+        return centres[rs.randint(0, len(centres), k)] + (rs.standard_normal((k, 3)) * extent).astype(np.float32)
+
+    rays = np.zeros(n, abi.ray_dtype)
+    k = n // 3
+    rays["origin"][:k] = scene.params["camera"][0]["position"]
+    rays["direction"][:k] = points(k) - rays["origin"][:k]
+    rays["t_max"][:k] = np.inf
+    a, b = points(n - k), points(n - k)
+    rays["origin"][k:] = a
+    rays["direction"][k:] = b - a
+    dist = np.linalg.norm(b - a, axis=1).astype(np.float32)
+    rays["t_max"][k:] = dist * np.where(rs.uniform(size=n - k) < 0.5, 1.0, rs.uniform(0.0, 3.0, n - k)).astype(np.float32)
+    ax = rs.randint(0, 3, 64)
+    rays["direction"][-64:] = 0
+    rays["direction"][-64:][np.arange(64), ax] = np.where(rs.uniform(size=64) < 0.5, -1.0, 1.0)
+    rays["t_max"][-64:] = np.inf
+    d = rays["direction"].astype(np.float64)
+    rays["direction"] = (d / np.maximum(np.linalg.norm(d, axis=1), 1e-30)[:, None]).astype(np.float32)    # unit length, like the shader's rays
+    return rays
+
+
+@pytest.mark.parametrize("bvh", [abi.BVH_LBVH, abi.BVH_SAH_REFINE, abi.BVH_LEAF_COLLAPSE, abi.BVH_LBVH | abi.BVH_WIDE, abi.BVH_SAH_REFINE | abi.BVH_WIDE],
+                         ids=["lbvh", "sah", "collapse", "lbvh-wide", "sah-wide"])
+@pytest.mark.parametrize("name", ["book1", "corne", "cirno", "voxel_city"])
+def test_ray_queries_closest_and_any(ctx, golden_dir, name, bvh):
+    """crt_rays_query: closest hits bit-exact (t bits and ID) against the oracle's hit_world, any-hit answers equal to
+    "the closest-hit query found something", also with t_max exactly at / one ulp below the closest hit."""
+    scene = abi.builtin_scene(name, 64, 64, golden_dir)
+    ctx.configure(64, 64)
+    ctx.upload(scene)
+    ctx.build(bvh)
+    rays = _query_rays(scene, 6000, 11)
+    ref = orc.hit_rays(scene, rays, flags=orc.TRAVERSE_FAST)
+    hit = ref["id"] != abi.ID_MISS
+    assert 0.15 < hit.mean() < 0.98
+    # boundary cases: the interval ends exactly at the hit (still found) and one ulp before it (the next one, or nothing)
+    edge = rays[hit][:1500].copy()
+    edge["t_max"] = ref["t"][hit][:1500]
+    below = edge.copy()
+    below["t_max"] = np.nextafter(edge["t_max"], np.float32(0))
+    allr = np.concatenate([rays, edge, below])
+    ref = orc.hit_rays(scene, allr, flags=orc.TRAVERSE_FAST)
+    assert np.array_equal(ref["id"][len(rays):len(rays) + len(edge)], ref["id"][:len(rays)][hit][:1500])
+    got = ctx.rays_query(allr, abi.QUERY_CLOSEST)
+    assert np.array_equal(got["id"], ref["id"]), f"{(got['id'] != ref['id']).sum()} closest-hit IDs differ"
+    h = ref["id"] != abi.ID_MISS
+    assert np.array_equal(got["t"][h].view(np.uint32), ref["t"][h].view(np.uint32))
+    anyh = ctx.rays_query(allr, abi.QUERY_ANY)
+    assert np.array_equal(anyh["id"] != abi.ID_MISS, h)
+    assert (anyh["t"][h] >= ref["t"][h]).all() and (anyh["t"][h] <= allr["t_max"][h]).all()
+    assert len(ctx.rays_query(allr[:0])) == 0
+
+
+def test_ray_query_large_batch_and_errors(ctx):
+    """Enough rays for the 64 sub-queues (more than 65536), device-resident stats untouched paths, argument errors."""
+    scene = abi.builtin_scene("book1", 64, 64)
+    ctx.configure(64, 64)
+    ctx.upload(scene)
+    with pytest.raises(abi.CrtError):
+        ctx.rays_query(np.zeros(1, abi.ray_dtype))           # no BVH yet
+    ctx.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE)
+    rays = np.tile(_query_rays(scene, 6000, 3), 20)[:100001]
+    ref = orc.hit_rays(scene, rays, flags=orc.TRAVERSE_FAST)
+    got = ctx.rays_query(rays)
+    assert np.array_equal(got["id"], ref["id"])
+    h = ref["id"] != abi.ID_MISS
+    assert np.array_equal(got["t"][h].view(np.uint32), ref["t"][h].view(np.uint32))
+    with pytest.raises(abi.CrtError):
+        ctx.rays_query(rays[:4], mode=7)
+    # a render after a query is unaffected (the query borrows the tracer's queues)
+    img, ids, ps = _gpu_render(ctx, scene, 64, 64, 2, bvh=abi.BVH_SAH_REFINE | abi.BVH_WIDE, tracer=abi.TRACER_WAVEFRONT)
+    ref_img, ref_ids, _ = orc.render(scene, ps, 64, 64, flags=orc.TRAVERSE_FAST)
+    assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32)) and np.array_equal(ids, ref_ids)
