@@ -99,8 +99,13 @@ def cpu_baseline(scene, target_s=12.0):
     _, _, c = orc.render(small, [small.params_for(i + 2, seeds[i + 1]) for i in range(n)], w, h, flags=orc.TRAVERSE_FAST,
                          threads=threads, want_ids=False)
     dt = time.perf_counter() - t0
-    return {"value": round(c.rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{small.name} {w}x{h} x {n} iterations ({c.rays} rays, {dt:.1f} s), oracle TRAVERSE_FAST, OpenMP"}
+    out = {"value": round(c.rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+           "sample": f"{small.name} {w}x{h} x {n} iterations ({c.rays} rays, {dt:.1f} s), oracle TRAVERSE_FAST, OpenMP"}
+    if scene.world is not None and scene.n_prims <= 300000:
+        # the reference builds its BVH on one host thread (B1, full-sweep SAH); restated in the oracle, whole scene
+        out["bvh_build_ms"] = round(orc.ref_bvh_build_ms(scene), 1)
+        out["bvh_build"] = "restated reference builder (BVHNode ctor + gpu_serialize), 1 thread, full scene"
+    return out
 
 
 def main():

@@ -61,23 +61,22 @@ __device__ __forceinline__ void prim_box(const BuildInput &in, uint32_t g, float
     }
 }
 
-__global__ void k_prim_bounds(BuildInput in, uint32_t n, float4 *plo, float4 *phi, uint32_t *scene_bounds) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    float c[3] = {0, 0, 0};
-    bool valid = g < n;
-    if (valid) {
+__global__ __launch_bounds__(256) void k_prim_bounds(BuildInput in, uint32_t n, float4 *plo, float4 *phi, uint32_t *scene_bounds) {
+    // grid-stride: the grid is capped (build_bvh) so that the atomics below stay a few thousand however large n is
+    uint32_t cmn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, cmx[3] = {0u, 0u, 0u};
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
         float lo[3], hi[3];
         prim_box(in, g, lo, hi);
         plo[g] = make_float4(lo[0], lo[1], lo[2], 0.0f);
         phi[g] = make_float4(hi[0], hi[1], hi[2], 0.0f);
-        for (int a = 0; a < 3; a++) c[a] = 0.5f * lo[a] + 0.5f * hi[a];
+        for (int a = 0; a < 3; a++) { const uint32_t e = enc_f(0.5f * lo[a] + 0.5f * hi[a]); cmn[a] = min(cmn[a], e); cmx[a] = max(cmx[a], e); }
     }
     // block-level min/max of the centroids (wave shuffles, then LDS), one atomic per block and axis: the six result
     // words are a single hot line, so the number of atomics, not their width, sets this kernel's time
     __shared__ uint32_t s_red[6][4];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int a = 0; a < 3; a++) {
-        uint32_t mn = valid ? enc_f(c[a]) : 0xFFFFFFFFu, mx = valid ? enc_f(c[a]) : 0u;
+        uint32_t mn = cmn[a], mx = cmx[a];
         for (int off = 32; off > 0; off >>= 1) {
             mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
             mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
@@ -305,22 +304,70 @@ __device__ __forceinline__ void refit_climb(const RefitArgs &A, uint32_t node, f
     }
 }
 
-// Stage 1: one thread per leaf.
+// Stage 1: one thread per leaf.  Everything a climber hands to its sibling inside the workgroup's range stays in LDS
+// (an inner node whose range lies in [blk_lo, blk_hi] has its own index in that interval: a Karras node sits at one
+// end of its range), so a level costs one round of independent global loads (parent, range, children) plus the
+// 128 bytes of the pair it emits; only parked nodes are written to the global node arrays for the next stage.
 __global__ __launch_bounds__(kRefitLeaves) void k_refit_leaves(RefitArgs A, uint32_t *list_out, uint32_t *count_out) {
+    __shared__ float4 s_lo[2 * kRefitLeaves], s_hi[2 * kRefitLeaves], s_info[2 * kRefitLeaves];      // [0, 256): inner nodes, [256, 512): leaves
+    __shared__ uint32_t s_flag[kRefitLeaves];
     __shared__ uint32_t s_count;
     if (threadIdx.x == 0) s_count = 0;
+    s_flag[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t j = blockIdx.x * kRefitLeaves + threadIdx.x;
-    if (j < (uint32_t)A.n) {
-        const uint32_t node = (uint32_t)(A.n - 1) + j;
+    const uint32_t blk_lo = blockIdx.x * kRefitLeaves, blk_hi = blk_lo + kRefitLeaves - 1u;
+    const uint32_t j = blk_lo + threadIdx.x;
+    const int n = A.n;
+    if (j < (uint32_t)n) {
+        uint32_t node = (uint32_t)(n - 1) + j;
         const uint32_t g = A.vals[j];
-        const float4 lo = A.plo[g], hi = A.phi[g];
+        float4 lo = A.plo[g], hi = A.phi[g];
         Sub sub;
         sub.count = 1; sub.kind_flags = A.leaf_count[j] >> 28; sub.first = j;
         sub.cost = A.c_isect * half_area(lo, hi);
-        A.nlo[node] = lo; A.nhi[node] = hi; A.ninfo[node] = sub_pack(sub);
-        const uint32_t blk_lo = blockIdx.x * kRefitLeaves;
-        refit_climb(A, node, lo, hi, sub, blk_lo, blk_lo + kRefitLeaves - 1u, &s_count, list_out + (size_t)blockIdx.x * kRefitCap);
+        s_lo[kRefitLeaves + threadIdx.x] = lo; s_hi[kRefitLeaves + threadIdx.x] = hi; s_info[kRefitLeaves + threadIdx.x] = sub_pack(sub);
+        uint32_t *list = list_out + (size_t)blockIdx.x * kRefitCap;
+        for (;;) {
+            const uint32_t p = A.parent[node];
+            if (p == 0xFFFFFFFFu) break;                                   // node is the root
+            const uint32_t rl = A.range_lo[p], rh = A.range_hi[p], cl = A.child_l[p], cr = A.child_r[p];
+            if (rl < blk_lo || rh > blk_hi) {                              // the parent belongs to a later stage: park
+                A.nlo[node] = lo; A.nhi[node] = hi; A.ninfo[node] = sub_pack(sub);
+                const uint32_t k = atomicAdd(&s_count, 1u);
+                if (k < kRefitCap) list[k] = node;
+                break;
+            }
+            const uint32_t lp = p - blk_lo;
+            // only LDS data changes hands here: fence the local address space alone, the pair stores stay in flight
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            const uint32_t old = __hip_atomic_fetch_add(&s_flag[lp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == 0u) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            const bool mine_left = cl == node;
+            const uint32_t sib = mine_left ? cr : cl;
+            const uint32_t ls = sib >= (uint32_t)(n - 1) ? kRefitLeaves + (sib - (uint32_t)(n - 1) - blk_lo) : sib - blk_lo;
+            const float4 slo = s_lo[ls], shi = s_hi[ls];
+            const Sub ssub = sub_unpack(s_info[ls]);
+            const float4 l_lo = mine_left ? lo : slo, l_hi = mine_left ? hi : shi;
+            const float4 r_lo = mine_left ? slo : lo, r_hi = mine_left ? shi : hi;
+            const Sub l_sub = mine_left ? sub : ssub, r_sub = mine_left ? ssub : sub;
+            write_child(A.pairs + 4 * (size_t)p, n, cl, l_lo, l_hi, l_sub, A.leaf_link);
+            write_child(A.pairs + 4 * (size_t)p + 2, n, cr, r_lo, r_hi, r_sub, A.leaf_link);
+            lo = make_float4(fminf(l_lo.x, r_lo.x), fminf(l_lo.y, r_lo.y), fminf(l_lo.z, r_lo.z), 0.0f);
+            hi = make_float4(fmaxf(l_hi.x, r_hi.x), fmaxf(l_hi.y, r_hi.y), fmaxf(l_hi.z, r_hi.z), 0.0f);
+            const float area = half_area(lo, hi);
+            const uint32_t lk = l_sub.kind_flags & 0xFFu, rk = r_sub.kind_flags & 0xFFu;
+            sub.count = l_sub.count + r_sub.count;
+            sub.first = l_sub.first;                       // the left child covers the lower part of the range
+            const uint32_t kind = (lk == rk) ? lk : kMixed;
+            const float as_inner = A.c_trav * area + l_sub.cost + r_sub.cost;
+            const float as_leaf = A.c_isect * (float)sub.count * area;
+            const bool collapse = kind != kMixed && sub.count <= A.max_leaf && as_leaf <= as_inner;
+            sub.cost = collapse ? as_leaf : as_inner;
+            sub.kind_flags = kind | (collapse ? kCollapsed : 0u);
+            s_lo[lp] = lo; s_hi[lp] = hi; s_info[lp] = sub_pack(sub);
+            node = p;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) count_out[blockIdx.x] = min(s_count, kRefitCap);
@@ -429,7 +476,7 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     if (!ensure(st.temp, std::max(sort_bytes, scan_bytes), err)) return false;
 
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, (uint32_t *)st.scene_bounds.ptr);
-    hipLaunchKernelGGL(k_prim_bounds, dim3(blocks), dim3(256), 0, stream, in, n, (float4 *)st.plo.ptr, (float4 *)st.phi.ptr,
+    hipLaunchKernelGGL(k_prim_bounds, dim3(std::min(blocks, 4096u)), dim3(256), 0, stream, in, n, (float4 *)st.plo.ptr, (float4 *)st.phi.ptr,
                        (uint32_t *)st.scene_bounds.ptr);
     hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, bits, (const float4 *)st.plo.ptr, (const float4 *)st.phi.ptr,
                        (const uint32_t *)st.scene_bounds.ptr, (uint64_t *)st.keys.ptr, (uint32_t *)st.vals.ptr);

@@ -52,6 +52,28 @@ __device__ __forceinline__ void read_half(const float4 *half, WideChild &c) {
     c.hi[0] = b.x; c.hi[1] = b.y; c.hi[2] = b.z; c.count = __float_as_uint(b.w);
 }
 
+// The eight children of a node under construction live in registers: every index into c[] below comes from a fully
+// unrolled loop (a dynamically indexed array would be placed in scratch memory, which made the first version of this
+// kernel several times slower), and "element k" for a run-time k is a chain of selects.
+__device__ __forceinline__ void take_if(WideChild &dst, const WideChild &v, bool p) {      // field-wise selects, never a conditional store
+#pragma unroll
+    for (int a = 0; a < 3; a++) { dst.lo[a] = p ? v.lo[a] : dst.lo[a]; dst.hi[a] = p ? v.hi[a] : dst.hi[a]; }
+    dst.link = p ? v.link : dst.link; dst.count = p ? v.count : dst.count;
+}
+struct WideSet {
+    WideChild c[8];
+    __device__ __forceinline__ WideChild get(int k) const {
+        WideChild r = c[0];
+#pragma unroll
+        for (int i = 1; i < 8; i++) take_if(r, c[i], i == k);
+        return r;
+    }
+    __device__ __forceinline__ void set(int k, const WideChild &v) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) take_if(c[i], v, i == k);
+    }
+};
+
 // level_count[l] = wide nodes of level l (queue length); level l reads queue l & 1 and appends to the other one.
 __global__ __launch_bounds__(128) void k_wide_level(const float4 *pairs, uint32_t level, uint32_t *level_count,
                                                     const uint2 *q_in, uint2 *q_out, float4 *wide, uint32_t stride_f4) {
@@ -61,38 +83,42 @@ __global__ __launch_bounds__(128) void k_wide_level(const float4 *pairs, uint32_
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
         const uint2 w = q_in[i];
         const uint32_t src = w.x, dst = w.y;
-        WideChild c[8];
+        WideSet S;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { for (int a = 0; a < 3; a++) { S.c[k].lo[a] = 0.0f; S.c[k].hi[a] = 0.0f; } S.c[k].link = 0u; S.c[k].count = 0u; }
         int n = 0;
         {
             WideChild a, b;
             read_half(pairs + 4 * (size_t)src, a);
             read_half(pairs + 4 * (size_t)src + 2, b);
-            if (!pad_leaf(a.count)) c[n++] = a;
-            if (!pad_leaf(b.count)) c[n++] = b;
+            if (!pad_leaf(a.count)) { S.set(n, a); n++; }
+            if (!pad_leaf(b.count)) { S.set(n, b); n++; }
         }
         while (n < 8) {
-            int best = -1; float best_area = -1.0f;
-            for (int k = 0; k < n; k++) {
-                if (c[k].count != 0u) continue;
-                float a = half_area3(c[k].lo, c[k].hi);
-                if (a > best_area) { best_area = a; best = k; }
+            int best = -1; float best_area = -1.0f; uint32_t best_link = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k >= n || S.c[k].count != 0u) continue;
+                const float a = half_area3(S.c[k].lo, S.c[k].hi);
+                if (a > best_area) { best_area = a; best = k; best_link = S.c[k].link; }
             }
             if (best < 0) break;
             WideChild a, b;
-            const uint32_t p = c[best].link;
-            read_half(pairs + 4 * (size_t)p, a);
-            read_half(pairs + 4 * (size_t)p + 2, b);
+            read_half(pairs + 4 * (size_t)best_link, a);
+            read_half(pairs + 4 * (size_t)best_link + 2, b);
             const bool pa = pad_leaf(a.count), pb = pad_leaf(b.count);
-            if (pa && pb) { c[best] = c[n - 1]; n--; continue; }
-            if (pa) { c[best] = b; continue; }
-            c[best] = a;
-            if (!pb) c[n++] = b;
+            if (pa && pb) { S.set(best, S.get(n - 1)); n--; continue; }
+            if (pa) { S.set(best, b); continue; }
+            S.set(best, a);
+            if (!pb) { S.set(n, b); n++; }
         }
         // node box, origin (rounded down to 15 mantissa bits) and per-axis grid step
         float lo[3], hi[3], origin[3]; uint32_t ebits[3]; double scale[3];
+#pragma unroll
         for (int a = 0; a < 3; a++) {
-            lo[a] = c[0].lo[a]; hi[a] = c[0].hi[a];
-            for (int k = 1; k < n; k++) { lo[a] = fminf(lo[a], c[k].lo[a]); hi[a] = fmaxf(hi[a], c[k].hi[a]); }
+            lo[a] = S.c[0].lo[a]; hi[a] = S.c[0].hi[a];
+#pragma unroll
+            for (int k = 1; k < 8; k++) if (k < n) { lo[a] = fminf(lo[a], S.c[k].lo[a]); hi[a] = fmaxf(hi[a], S.c[k].hi[a]); }
             uint32_t b = __float_as_uint(lo[a]), t = b & 0xFFFFFE00u;
             if ((b & 0x80000000u) && t != b) t += 0x200u;          // negative: truncation moved it up, step one unit down
             origin[a] = __uint_as_float(t);
@@ -103,66 +129,73 @@ __global__ __launch_bounds__(128) void k_wide_level(const float4 *pairs, uint32_
             ebits[a] = (uint32_t)(e + 127);
             scale[a] = ldexp(1.0, e);
         }
-        // slot assignment: greedy maximum of sum_a (slot bit a ? +1 : -1) * (child centroid - node centre)_a
-        int slot_of[8]; bool slot_used[8], child_done[8];
-        for (int k = 0; k < 8; k++) { slot_used[k] = false; child_done[k] = false; slot_of[k] = -1; }
+        // slot assignment: greedy maximum of sum_a (slot bit a ? +1 : -1) * (child centroid - node centre)_a.
+        // slot_of: four bits per child; used / done: one bit per slot / child.
         float dv[8][3];
-        for (int k = 0; k < n; k++)
-            for (int a = 0; a < 3; a++) dv[k][a] = (0.5f * c[k].lo[a] + 0.5f * c[k].hi[a]) - (0.5f * lo[a] + 0.5f * hi[a]);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) dv[k][a] = (0.5f * S.c[k].lo[a] + 0.5f * S.c[k].hi[a]) - (0.5f * lo[a] + 0.5f * hi[a]);
+        uint32_t slot_of = 0, slot_used = 0, child_done = 0;
         for (int it = 0; it < n; it++) {
             float best = -3.402823466e38f; int bk = -1, bs = -1;
-            for (int k = 0; k < n; k++) {
-                if (child_done[k]) continue;
-                for (int s = 0; s < 8; s++) {
-                    if (slot_used[s]) continue;
-                    float v = ((s & 1) ? dv[k][0] : -dv[k][0]) + ((s & 2) ? dv[k][1] : -dv[k][1]) + ((s & 4) ? dv[k][2] : -dv[k][2]);
-                    if (v > best) { best = v; bk = k; bs = s; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k >= n || ((child_done >> k) & 1u)) continue;
+#pragma unroll
+                for (int sl = 0; sl < 8; sl++) {
+                    if ((slot_used >> sl) & 1u) continue;
+                    const float v = ((sl & 1) ? dv[k][0] : -dv[k][0]) + ((sl & 2) ? dv[k][1] : -dv[k][1]) + ((sl & 4) ? dv[k][2] : -dv[k][2]);
+                    if (v > best) { best = v; bk = k; bs = sl; }
                 }
             }
             if (bk < 0) {            // only NaN costs left: first free pair
-                for (int k = 0; k < n && bk < 0; k++) if (!child_done[k]) bk = k;
-                for (int s = 0; s < 8 && bs < 0; s++) if (!slot_used[s]) bs = s;
+                bk = __builtin_ctz(~child_done & ((1u << n) - 1u));
+                bs = __builtin_ctz(~slot_used & 0xFFu);
             }
-            slot_of[bk] = bs; child_done[bk] = true; slot_used[bs] = true;
+            slot_of |= (uint32_t)bs << (4 * bk); child_done |= 1u << bk; slot_used |= 1u << bs;
         }
-        int child_in[8];
-        for (int s = 0; s < 8; s++) child_in[s] = -1;
-        for (int k = 0; k < n; k++) child_in[slot_of[k]] = k;
         uint32_t imask = 0, n_inner = 0;
-        for (int s = 0; s < 8; s++) if (child_in[s] >= 0 && c[child_in[s]].count == 0u) { imask |= 1u << s; n_inner++; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (k < n && S.c[k].count == 0u) { imask |= 1u << ((slot_of >> (4 * k)) & 7u); n_inner++; }
         uint32_t qpos = 0;
         if (n_inner) qpos = atomicAdd(&level_count[level + 1], n_inner);
         const uint32_t child_base = next_base + qpos;
-        // quantise
-        uint32_t q[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};     // qlo x,y,z, qhi x,y,z; two dwords of four slots
+        // quantise: empty slots keep qlo = 255, qhi = 0
+        uint32_t q[6][2];     // qlo x,y,z, qhi x,y,z; two dwords of four slots
         uint32_t link[8];
-        uint32_t r = 0;
-        for (int s = 0; s < 8; s++) {
-            const int k = child_in[s];
-            const uint32_t sh = 8u * (uint32_t)(s & 3), wd = (uint32_t)(s >> 2);
-            if (k < 0) {
-                for (int a = 0; a < 3; a++) q[a][wd] |= 255u << sh;
-                link[s] = kWideEmptyLink;
-                continue;
-            }
+#pragma unroll
+        for (int a = 0; a < 3; a++) { q[a][0] = q[a][1] = 0xFFFFFFFFu; q[3 + a][0] = q[3 + a][1] = 0u; }
+#pragma unroll
+        for (int sl = 0; sl < 8; sl++) link[sl] = kWideEmptyLink;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (k >= n) continue;
+            const uint32_t sl = (slot_of >> (4 * k)) & 7u, sh = 8u * (sl & 3u);
+            const bool upper = sl >= 4u;
+#pragma unroll
             for (int a = 0; a < 3; a++) {
                 const double o = (double)origin[a], sc = scale[a];
-                double fl = floor(((double)c[k].lo[a] - o) / sc), fh = ceil(((double)c[k].hi[a] - o) / sc);
+                double fl = floor(((double)S.c[k].lo[a] - o) / sc), fh = ceil(((double)S.c[k].hi[a] - o) / sc);
                 fl = fl < 0.0 ? 0.0 : fl > 255.0 ? 255.0 : fl;
                 fh = fh < 0.0 ? 0.0 : fh > 255.0 ? 255.0 : fh;
-                while (fl > 0.0 && o + fl * sc > (double)c[k].lo[a]) fl -= 1.0;
-                while (fh < 255.0 && o + fh * sc < (double)c[k].hi[a]) fh += 1.0;
-                q[a][wd] |= (uint32_t)fl << sh;
-                q[3 + a][wd] |= (uint32_t)fh << sh;
+                while (fl > 0.0 && o + fl * sc > (double)S.c[k].lo[a]) fl -= 1.0;
+                while (fh < 255.0 && o + fh * sc < (double)S.c[k].hi[a]) fh += 1.0;
+                const uint32_t clr = ~(255u << sh), vl = (uint32_t)fl << sh, vh = (uint32_t)fh << sh;
+                if (upper) { q[a][1] = (q[a][1] & clr) | vl; q[3 + a][1] |= vh; }
+                else { q[a][0] = (q[a][0] & clr) | vl; q[3 + a][0] |= vh; }
             }
-            if (c[k].count == 0u) {
-                link[s] = child_base + r;
-                q_out[qpos + r] = make_uint2(c[k].link, child_base + r);
-                r++;
+            uint32_t lk;
+            if (S.c[k].count == 0u) {
+                const uint32_t r = (uint32_t)__builtin_popcount(imask & ((1u << sl) - 1u));     // inner children are numbered in slot order
+                lk = child_base + r;
+                q_out[qpos + r] = make_uint2(S.c[k].link, lk);
             } else {
-                const uint32_t kind = c[k].count >> 28, cnt = c[k].count & 0x0FFFFFFFu;
-                link[s] = kWideLeafTag | (kind << 29) | ((cnt - 1u) << 26) | c[k].link;
+                const uint32_t kind = S.c[k].count >> 28, cnt = S.c[k].count & 0x0FFFFFFFu;
+                lk = kWideLeafTag | (kind << 29) | ((cnt - 1u) << 26) | S.c[k].link;
             }
+#pragma unroll
+            for (int s2 = 0; s2 < 8; s2++) link[s2] = (uint32_t)s2 == sl ? lk : link[s2];
         }
         float4 *o = wide + (size_t)stride_f4 * dst;
         o[0] = make_float4(__uint_as_float(__float_as_uint(origin[0]) | ebits[0]), __uint_as_float(__float_as_uint(origin[1]) | ebits[1]),

@@ -146,6 +146,16 @@ def ref_bvh(scene):
     return nodes, ids[0], ids[1], ids[2]
 
 
+def ref_bvh_build_ms(scene):
+    """Wall time of ONE run of the restated reference builder (B1 + B2, single-threaded like the reference) on scene.world."""
+    import time
+    ref = SceneRef(scene)
+    n = [C.c_uint32() for _ in range(4)]
+    t0 = time.perf_counter()
+    lib.orc_ref_bvh(C.byref(ref.s), C.byref(ref.w), None, C.byref(n[0]), None, C.byref(n[1]), None, C.byref(n[2]), None, C.byref(n[3]))
+    return (time.perf_counter() - t0) * 1e3
+
+
 def math_fn(fn, a, b=None, libm=False):
     a = np.ascontiguousarray(a, dtype=np.float32)
     b = np.ascontiguousarray(b if b is not None else np.zeros_like(a), dtype=np.float32)
