@@ -348,6 +348,16 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
                         if (base < n) { pool_base = s * q.shard_cap; pool_next = base; pool_end = min(n, base + 64u * fetch); break; }
                     }
                     k++;
+                    // Skip the exhausted sub-queues that follow with ONE round of loads: lane j looks at the (k + j)-th
+                    // sub-queue of the steal order (ns <= 64).  Walking them one dependent load at a time cost every
+                    // wave ~100 us at the end of every launch, most of a late bounce's launch.
+                    {
+                        const uint32_t kk = k + lane;
+                        const uint32_t sl = ns >= 8 ? (home + 8 * (kk % per) + (kk / per)) % ns : (home + kk) % ns;
+                        const bool live = kk < ns && *(volatile uint32_t *)(cursors + sl * kCtrStride) < counts[sl * kCtrStride];
+                        const unsigned long long m = __ballot(live);
+                        k = m ? k + (uint32_t)__builtin_ctzll(m) : ns;
+                    }
                 }
                 if (k >= ns) drained = true;
             }
