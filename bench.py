@@ -3,8 +3,11 @@
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--tracer megakernel|wavefront]
 
-A "step" is one dispatch of the hot path = one sample per pixel over the whole frame (what one
-vkCmdDispatch does in the reference, engine/src/vk_engine.cpp:1435).  The default workload is the one
+A "step" is one pass of the hot path over one batch of input: --spp-per-step (default 16) consecutive
+samples per pixel over the whole frame, i.e. 16 of the reference's vkCmdDispatch calls
+(engine/src/vk_engine.cpp:1435) handed to crt_render together, which is the unit the wavefront tracer
+traces at once; the 256 spp of the headline config are 16 steps.  The per-frame-rebuild workload keeps
+one frame (animate + rebuild + 1 spp) per step.  The default workload is the one
 BASELINE.json's metric is quoted on, lost_empire 4K: lost_empire.obj is absent from the reference
 checkout, so the documented stand-in `voxel_city(seed=1)` (224,998 triangles, one atlas texture) is
 rendered at 3840x2160 and labelled as such.  With N > 1 (launched by torch.distributed.run, one rank per
@@ -115,6 +118,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="lost_empire_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--tracer", default=os.environ.get("CRT_TRACER", "wavefront"), choices=["megakernel", "wavefront"])
+    ap.add_argument("--spp-per-step", type=int, default=16, help="iterations (samples per pixel) per step; static-scene workloads only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bvh", default=os.environ.get("CRT_BVH", ""), choices=["", "lbvh", "sah", "collapse", "lbvh-wide", "sah-wide"],
                     help="default: sah-wide (static scenes), lbvh-wide for the per-frame rebuild workload")
@@ -153,11 +157,14 @@ def main():
     wide = args.bvh.endswith("-wide") and tracer == abi.TRACER_WAVEFRONT
     build_ms = ctx.build(bvh_flags)
     build_ms = ctx.build(bvh_flags)   # second build: allocations are warm, this is the device time of the build alone
-    seeds = abi.frame_seeds(0, args.warmup + args.steps + 1)
+    spp = 1 if rebuild else max(1, args.spp_per_step)
+    seeds = abi.frame_seeds(0, (args.warmup + args.steps) * spp + 1)
 
-    def run(first_iter, n):
+    def run(first_step, n):
+        """Steps first_step .. first_step + n - 1 (1-based); step k covers iterations (k - 1) * spp + 1 .. k * spp."""
+        first_iter = (first_step - 1) * spp + 1
         if not rebuild:
-            ctx.render(scene.params, first_iter, seeds[first_iter - 1:first_iter - 1 + n])
+            ctx.render(scene.params, first_iter, seeds[first_iter - 1:first_iter - 1 + n * spp])
             return
         for i in range(n):            # config 5: animate + full rebuild every frame, one sample per frame
             ctx.animate(float(first_iter + i), 0.35)
@@ -230,8 +237,8 @@ def main():
             launch_ms = st.last_extend_ms / st.last_extend_launches
         else:
             kernel_name, kernel_bytes_per_ray = "k_megakernel", bytes_per_ray
-            n_launches = float(args.steps)
-            launch_ms = kernel_ms / args.steps if not rebuild else kernel_ms
+            n_launches = float(args.steps * spp)
+            launch_ms = kernel_ms / (args.steps * spp) if not rebuild else kernel_ms
         launch_rays = rank_rays / n_launches
         achieved = launch_rays * kernel_bytes_per_ray / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         line = {
@@ -239,7 +246,7 @@ def main():
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": label, "scene": scene_name, "width": W, "height": H, "spp_per_step": 1,
+            "config": {"workload": label, "scene": scene_name, "width": W, "height": H, "spp_per_step": spp,
                        "tris": int(len(scene.tris)), "spheres": int(len(scene.spheres)), "quads": int(len(scene.quads)),
                        "tracer": args.tracer, "bvh": args.bvh, "rng": "ref-hash", "parallelism": f"tile{world}" if world > 1 else "single",
                        "bvh_build_ms": round(build_ms, 4), "gather_ms": None if gather_ms is None else round(gather_ms, 3),

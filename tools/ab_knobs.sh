@@ -1,4 +1,4 @@
-run() { timeout -k 10 120 python bench.py --no-cpu-baseline --steps 32 --warmup 16 "$@" | python -c "
+run() { timeout -k 10 120 python bench.py --no-cpu-baseline --steps 4 --warmup 1 "$@" | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); c=d['config']; print(d['value'], 'Mrays/s  ms/step', d['ms_per_step'], 'ext_ms', d['roofline']['launch_ms'])"; }
 echo "== base"; run

@@ -1,6 +1,6 @@
 # usage: tools/pmc_passes.sh outdir  -- one rocprofv3 --pmc run per counter group (each within the per-block slot limits)
 out=$1; mkdir -p $out
-cmd="python3 bench.py --steps 16 --warmup 16 --no-cpu-baseline $PMC_BENCH_ARGS"
+cmd="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline $PMC_BENCH_ARGS"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
            "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
