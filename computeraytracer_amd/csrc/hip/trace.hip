@@ -181,7 +181,6 @@ struct WfQueues {
     uint32_t *cursors;      // [kMaxBounces][kShards]     extend's work-fetch cursor
     uint32_t tiles_per_shard, shard_cap;   // shard_cap = tiles_per_shard * 64 slots
     uint32_t n_shards;                     // sub-queues in use (<= kShards)
-    uint32_t precheck;                     // experiment knob: load the cursor before the fetch atomic
     uint32_t refill;                       // idle lanes that trigger a refill
     uint32_t leaf_lanes;                   // lanes waiting at a leaf that trigger a leaf-test phase
     uint32_t lds_depth;                    // LDS stack entries per lane (lower only with CRT_FLAG_DEBUG_SMALL_STACK)
@@ -527,8 +526,6 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     static const uint32_t env_shards = [] { const char *e = getenv("CRT_WF_SHARDS"); int v = e ? atoi(e) : 64;
                                             return (uint32_t)((v >= 1 && v <= 64 && (v & (v - 1)) == 0) ? v : 64); }();     // k_wf_shade: one lane per sub-queue
     q.n_shards = env_shards;
-    static const uint32_t env_precheck = [] { const char *e = getenv("CRT_WF_PRECHECK"); return (uint32_t)(e ? atoi(e) : 1); }();
-    q.precheck = env_precheck;
     static const uint32_t env_refill = [] { const char *e = getenv("CRT_WF_REFILL"); int v = e ? atoi(e) : (int)kRefillLanes; return (uint32_t)(v < 1 ? 1 : v > 64 ? 64 : v); }();
     q.refill = env_refill;
     static const uint32_t env_leaf = [] { const char *e = getenv("CRT_WF_LEAF_LANES"); int v = e ? atoi(e) : 16; return (uint32_t)(v < 1 ? 1 : v > 64 ? 64 : v); }();
@@ -630,7 +627,7 @@ bool launch_ray_query(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     WfQueues q;
     const uint32_t n_tiles = (n_rays + 63) / 64;
     q.n_shards = n_tiles >= 64 * 16 ? 64 : 1;                    // sub-queues only pay once every wave can have its own chunks
-    q.precheck = 1; q.refill = kRefillLanes; q.leaf_lanes = 16;
+    q.refill = kRefillLanes; q.leaf_lanes = 16;
     q.tiles_per_shard = (n_tiles + q.n_shards - 1) / q.n_shards;
     q.shard_cap = q.tiles_per_shard * 64;
     const size_t cap = (size_t)q.shard_cap * q.n_shards;
