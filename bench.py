@@ -143,7 +143,12 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     scene_name, W, H, label = WORKLOADS[args.workload]
-    scene = abi.builtin_scene(scene_name, W, H, os.path.join(ROOT, "tests", "golden"))
+    asset_dir = os.path.join(ROOT, "tests", "golden")
+    real = os.path.join(ROOT, "assets")
+    if args.workload == "lost_empire_4k" and any(os.path.exists(os.path.join(real, "lost_empire" + e)) for e in (".mesh", ".obj")):
+        # the real mesh when a checkout supplies it (the reference's own copy is absent)
+        scene_name, asset_dir, label = "lost_empire", real, "lost_empire.obj 4K (mesh supplied under assets/)"
+    scene = abi.builtin_scene(scene_name, W, H, asset_dir)
     tracer = abi.TRACER_WAVEFRONT if args.tracer == "wavefront" else abi.TRACER_MEGAKERNEL
     rebuild = args.workload == "grid10m_1080p"
     if not args.bvh:

@@ -251,6 +251,31 @@ static void scene_voxel_city(SceneBuilder &b, uint32_t seed, float aspect) {
     b.set_background({-1, -1, -1});
 }
 
+// BASELINE config 4 with the real mesh, for a checkout that has it: <asset_dir>/lost_empire.mesh or .obj
+// as Tris with one Lambertian textured by "lost_empire-RGBA" (<asset_dir>/lost_empire-RGBA.tx when present, else the
+// atlas stand-in), default sky.  The reference never renders this mesh through the path tracer, so the camera is
+// this harness's: from above a corner of the bounding box towards its centre.
+static bool scene_lost_empire(SceneBuilder &b, const std::string &asset_dir, float aspect, std::string &err) {
+    std::vector<MeshVertex> verts;
+    if (!find_mesh(asset_dir, "lost_empire", verts, err)) return false;
+    if (verts.size() < 3) { err = "lost_empire: empty mesh"; return false; }
+    uint32_t mat = b.lambertian_tex("lost_empire-RGBA");
+    float lo[3] = {verts[0].pos[0], verts[0].pos[1], verts[0].pos[2]}, hi[3] = {lo[0], lo[1], lo[2]};
+    for (size_t i = 0; i + 2 < verts.size(); i += 3) {
+        const MeshVertex &a = verts[i], &c = verts[i + 1], &d = verts[i + 2];
+        b.push_object(b.add_tri({a.pos[0], a.pos[1], a.pos[2]}, {c.pos[0], c.pos[1], c.pos[2]}, {d.pos[0], d.pos[1], d.pos[2]},
+                                {a.uv[0], c.uv[0], d.uv[0]}, {a.uv[1], c.uv[1], d.uv[1]}, mat));
+        for (int k = 0; k < 3; k++) for (int ax = 0; ax < 3; ax++) {
+            lo[ax] = std::fmin(lo[ax], verts[i + k].pos[ax]); hi[ax] = std::fmax(hi[ax], verts[i + k].pos[ax]);
+        }
+    }
+    const f3c centre = {0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    b.set_camera({centre.x - 0.55f * ex, centre.y + 0.45f * ey + 0.1f * (ex + ez), centre.z - 0.65f * ez}, centre, 55.0f, aspect, 0.0f, 10.0f);
+    b.set_background({-1, -1, -1});
+    return true;
+}
+
 // BASELINE config 5: n x n instances of one 1,000-triangle patch (20 x 25 cells,
 // two CCW-from-above triangles per cell), flattened to world space, rest pose y = 0.
 static void scene_grid(SceneBuilder &b, uint32_t n, float aspect) {
@@ -291,6 +316,7 @@ int crt_scene_builtin(const char *name, const char *asset_dir, uint32_t width, u
     else if (n == "cirno") { ok = scene_cirno(b, dir, aspect, err); bind_textures(b, dir, {{"fumo_diffuse", "cirno_low_u1_v1.tx"}, {"fumo_diffuse", "earthmap.tx"}}); }
     else if (n == "monkey") ok = scene_monkey(b, dir, aspect, err);
     else if (n == "voxel_city") { scene_voxel_city(b, 1, aspect); bind_textures(b, dir, {}); }
+    else if (n == "lost_empire") { ok = scene_lost_empire(b, dir, aspect, err); bind_textures(b, dir, {{"lost_empire-RGBA", "lost_empire-RGBA.tx"}}); }
     else if (n == "grid10m") scene_grid(b, 100, aspect);
     else if (n.rfind("grid:", 0) == 0) {
         int k = atoi(n.c_str() + 5);

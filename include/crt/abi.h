@@ -170,7 +170,7 @@ void crt_quad_init(crt_quad *q, const float corner[3], const float u[3], const f
 
 /* Built-in scenes: the reference's four (vk_engine.cpp:825-926: "book1",
  * "quads", "corne", "cirno") and the benchmark ones ("monkey", "voxel_city",
- * "grid10m").  mesh/texture inputs come from files under asset_dir where a
+ * "grid10m", and "lost_empire" for a checkout that has lost_empire.obj/.mesh).  mesh/texture inputs come from files under asset_dir where a
  * scene needs them.  The returned scene owns its arrays until crt_scene_free. */
 typedef struct crt_host_scene crt_host_scene;
 int crt_scene_builtin(const char *name, const char *asset_dir, uint32_t width, uint32_t height, crt_host_scene **out);

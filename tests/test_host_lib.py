@@ -180,3 +180,17 @@ def test_band_rows_partition():
             assert np.array_equal(allr, np.arange(h))
             for r in range(world):
                 assert all((y // 8) % world == r for y in rows[r])
+
+
+def test_lost_empire_scene_uses_a_supplied_mesh(tmp_path):
+    """Config 4 with the real mesh: absent here, so a tiny stand-in file under the same name checks the plumbing."""
+    with pytest.raises(abi.CrtError):
+        abi.builtin_scene("lost_empire", 64, 36, str(tmp_path))          # no mesh: an error, not a silent substitute
+    (tmp_path / "lost_empire.obj").write_text("v 0 0 0\nv 4 0 0\nv 4 2 0\nv 0 2 8\nvt 0 0\nvt 1 0\nvt 1 1\nf 1/1 2/2 3/3\nf 1/1 3/3 4/2\n")
+    s = abi.builtin_scene("lost_empire", 64, 36, str(tmp_path))
+    assert len(s.tris) == 2 and len(s.spheres) == 0 and len(s.materials) == 1
+    assert int(s.materials["type"][0]) == 1 and int(s.materials["textureIndex"][0]) == 0 and len(s.textures) == 1
+    cam = s.params["camera"][0]
+    assert np.isfinite(cam["position"]).all() and cam["position"][1] > 1.0       # above the box, looking at its centre
+    offs, prims, is_list = s.world
+    assert list(offs) == [0, 1, 2] and not is_list.any()
