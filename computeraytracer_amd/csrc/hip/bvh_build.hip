@@ -4,7 +4,7 @@
 //
 // Pipeline (all on the context's stream, no host round trips):
 //   1. k_prim_bounds   padded AABB + centroid per primitive, scene centroid bounds (atomic min/max)
-//   2. k_morton        Morton code of the centroid, 10..21 bits per axis by primitive count (64-bit keys)
+//   2. k_morton        Morton code of the centroid, 21 bits per axis on a grid of cubic cells (63-bit keys)
 //   3. radix sort      (code, primitive) pairs, rocPRIM
 //   4. kind ranks      exclusive scans of "is sphere" / "is quad" over the sorted order, rocPRIM
 //   5. k_pack          traversal records per kind in sorted order (tri 48 B, sphere 16 B, quad 64 B)
@@ -103,7 +103,7 @@ __device__ __forceinline__ uint64_t expand_bits21(uint64_t v) {
     return v;
 }
 
-// Morton code of the centroid, `bits` per axis (10..21, chosen from the primitive count: cells finer than the
+// Morton code of the centroid, `bits` per axis (cells finer than the
 // primitives' spacing keep equal codes, which the hierarchy can only split by index, rare).
 __global__ void k_morton(uint32_t n, uint32_t bits, const float4 *plo, const float4 *phi, const uint32_t *scene_bounds,
                          uint64_t *keys, uint32_t *vals) {
@@ -113,9 +113,12 @@ __global__ void k_morton(uint32_t n, uint32_t bits, const float4 *plo, const flo
     float c[3] = {0.5f * lo.x + 0.5f * hi.x, 0.5f * lo.y + 0.5f * hi.y, 0.5f * lo.z + 0.5f * hi.z};
     const float cells = (float)(1u << bits);
     uint64_t q[3];
+    // one scale for all axes (cubic Morton cells): normalising each axis by its own extent would spend as many splits
+    // on the thin axis of a flat scene (a terrain, a city) as on the long ones and cut it into overlapping slabs
+    float ext = 0.0f;
+    for (int a = 0; a < 3; a++) ext = fmaxf(ext, dec_f(scene_bounds[3 + a]) - dec_f(scene_bounds[a]));
     for (int a = 0; a < 3; a++) {
-        float mn = dec_f(scene_bounds[a]), mx = dec_f(scene_bounds[3 + a]);
-        float ext = mx - mn;
+        float mn = dec_f(scene_bounds[a]);
         float f = ext > 0.0f ? (c[a] - mn) / ext : 0.0f;
         q[a] = (uint64_t)fminf(fmaxf(f * cells, 0.0f), cells - 1.0f);
     }
@@ -463,10 +466,16 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
 
     // temp storage for rocPRIM (sized for the larger of sort and scan)
     size_t sort_bytes = 0, scan_bytes = 0;
-    // bits per axis: one more than half of log2(n) (surfaces are 2-D sets), within 10..21
-    uint32_t bits = 1;
-    while ((1ull << (2 * (bits - 1))) < (uint64_t)n && bits < 21) bits++;
-    bits = bits < 10 ? 10 : bits;
+    // The grid has cubic cells over the LARGEST extent of the centroids (k_morton), and one far-away primitive (the
+    // reference scenes' ground sphere of radius 2000) must not leave a whole mesh in a single cell: 21 bits per axis
+    // whenever the sort's cost does not depend on the key width (rocPRIM merge-sorts below about a million keys);
+    // above that, four more than half of log2(n) (surfaces are 2-D sets), which saves a radix pass at 10 M.
+    uint32_t bits = 21;
+    if (n > (1u << 20)) {
+        bits = 1;
+        while ((1ull << (2 * (bits - 1))) < (uint64_t)n && bits < 21) bits++;
+        bits = bits + 4 > 21 ? 21 : bits + 4;
+    }
     const unsigned key_bits = 3 * bits;
     rocprim::double_buffer<uint64_t> dkeys((uint64_t *)st.keys.ptr, (uint64_t *)st.keys_alt.ptr);
     rocprim::double_buffer<uint32_t> dvals((uint32_t *)st.vals.ptr, (uint32_t *)st.vals_alt.ptr);
