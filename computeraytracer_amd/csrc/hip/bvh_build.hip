@@ -2,15 +2,17 @@
 // raytracing/src/bounding_volume_hierarchy.cpp:5-130, rows B1-B3 of SURVEY.md
 // section 8(a)).
 //
-// Pipeline (all on the context's stream, no host round trips):
+// Pipeline (all on the context's stream; steps 1-7 without host round trips):
 //   1. k_prim_bounds   padded AABB + centroid per primitive, scene centroid bounds (atomic min/max)
 //   2. k_morton        Morton code of the centroid, 21 bits per axis on a grid of cubic cells (63-bit keys)
 //   3. radix sort      (code, primitive) pairs, rocPRIM
 //   4. kind ranks      exclusive scans of "is sphere" / "is quad" over the sorted order, rocPRIM
 //   5. k_pack          traversal records per kind in sorted order (tri 48 B, sphere 16 B, quad 64 B)
 //   6. k_hierarchy     Karras 2012: one thread per inner node finds its range, split and children
-//   7. k_refit_emit    bottom-up: the second thread to reach a node unions its children's boxes and
-//                      writes the node's 64-byte sibling pair (the traversal format)
+//   7. k_refit_leaves / k_refit_resume   bottom-up in stages that never leave workgroup scope: the second climber to
+//                      reach a node unions its children's boxes and writes the node's 64-byte sibling pair
+//                      (the traversal format)
+//   8. optional: SAH refinement (bvh_sah.hip), collapse into 8-wide quantised nodes (bvh_wide.hip)
 // The reference's tree is different (full-sweep SAH, threaded links); closest hits do not depend on
 // the tree because acceptance is order-independent (intersect.h).
 #include <hip/hip_runtime.h>

@@ -148,26 +148,29 @@ bool launch_megakernel(hipStream_t stream, const DeviceSceneHost &sch, const Fra
 }
 
 // ------------------------------------------------------------------------------------------------
-// Wavefront tracer.  One dispatch = init -> generate -> [extend -> shade+compact] x max_bounces.
+// Wavefront tracer.  One launch sequence = init -> generate -> [extend -> shade+compact] x max_bounces -> accumulate,
+// over a batch of n_batch consecutive iterations (crt_render) whose paths share the queues.
 //
-//   queue entry (64 B, SoA over four float4 arrays, two queues used ping-pong):
-//     ray_o = {origin.xyz, -}            ray_d = {direction.xyz, pixel slot in the packed band buffer}
-//     thr   = {color.rgb, rng word 1};  ray_o's spare lane holds rng word 0, ray_d's the pixel slot | batch index << 26.
+//   queue entry (48 B, SoA over three float4 arrays, two queues used ping-pong):
+//     ray_o = {origin.xyz, rng word 0}    ray_d = {direction.xyz, batch index << 26 | pixel slot in the packed band buffer}
+//     thr   = {color.rgb, rng word 1}
 //     ray_color's emittedColor is not carried: a path that meets an emitter ends there (scatter() is false for a light,
 //     compute.comp:416-418), so it is zero for every path still in a queue.
 //   hit[i] = {t, id} of queue entry i (8 B), written by extend, read by shade.
+//   pass[b][pixel] = radiance of iteration b's path through that pixel (16 B), written by shade when the path ends
+//     (each pixel owns exactly one path per iteration), added to the image in iteration order by k_wf_accumulate:
+//     main()'s read-modify-write (compute.comp:470-476), so a batch gives the bits n_batch dispatches would.
 //
-// The queue is split into kShards sub-queues (contiguous runs of 8x8 tiles).  A path never leaves its
-// sub-queue, so a sub-queue's capacity is its initial size and every sub-queue has its own size and
-// work-cursor words: one returning atomic on ONE word saturates near 88 per microsecond on this chip
+// The queue is split into sub-queues (contiguous runs of 8x8 tiles; 64 in use, kShards is the counter table's
+// stride).  A path never leaves its sub-queue, so a sub-queue's capacity is its initial size and every sub-queue has
+// its own size and work-cursor words: one returning atomic on ONE word saturates near 88 per microsecond on this chip
 // (MI355X_MICROARCH.md, "dequeue"), which at one atomic per 64 rays capped a single-counter version of
 // this design at ~5.6 Grays/s before any traversal work.
 //
 // extend is persistent: a fixed grid of waves pulls 64-ray batches from its home sub-queue, then steals
 // from the others, until everything is drained; a late bounce with few rays costs one short launch.
-// shade ends a path by doing main()'s read-modify-write of the accumulation pixel directly (each pixel
-// owns exactly one path per dispatch) and appends survivors to the other queue with a wave ballot +
-// prefix count and a single atomic per wave on the sub-queue's own counter.
+// shade appends survivors to the other queue with a wave ballot + prefix count and a single atomic per wave on the
+// sub-queue's own counter.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kShards = 256;
 constexpr uint32_t kMaxBounces = 16;
