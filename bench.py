@@ -28,7 +28,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("CRT_BENCH_FORCE_DIST", "") == "1":
     # PyTorch-ROCm bundles its own HIP runtime (same soname as /opt/rocm's).  Loaded first, libcrt.so binds to that one
     # copy; loaded second, the process ends up with two runtimes and the second cannot open the GPU.
     import torch  # noqa: F401,E402
@@ -133,7 +133,9 @@ def main():
     rehearse = os.environ.get("CRT_BENCH_REHEARSE", "") == "1"
     if rehearse:
         local_rank = 0
-    if world > 1:
+    # CRT_BENCH_FORCE_DIST=1: take the torch.distributed path even with one rank (RCCL init, all-reduce and all-gather
+    # next to libcrt.so in one process can then be checked on a one-GPU box); never set by the driver
+    if world > 1 or os.environ.get("CRT_BENCH_FORCE_DIST", "") == "1":
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
