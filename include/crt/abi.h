@@ -57,6 +57,11 @@ int crt_configure(crt_context *ctx, const crt_config *cfg);
  * init_descriptors (vk_engine.cpp:1177-1229).  Invalidates any BVH. */
 int crt_scene_upload(crt_context *ctx, const crt_scene_desc *scene);
 
+/* Limits (every one is checked and reported as an error, never a wrong image): fewer than 2^30 primitives of a kind
+ * (ID tag), width x height below 2^31; the wavefront tracer and crt_rays_query take up to 2^26 - 2 primitives and
+ * 16 bounces; CRT_BVH_WIDE up to 2^24 - 1 primitives and 64 levels; a wavefront batch needs fewer than 2^26 - 1
+ * pixels per context (larger frames render one iteration per launch sequence). */
+
 /* Replaces BVHNode::BVHNode + gpu_serialize on the host
  * (raytracing/src/bounding_volume_hierarchy.cpp:63-130) with a device-side
  * build over the uploaded primitives.  flags: CRT_BVH_*.  build_ms (optional)
