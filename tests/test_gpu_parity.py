@@ -571,3 +571,31 @@ def test_ray_query_large_batch_and_errors(ctx):
     img, ids, ps = _gpu_render(ctx, scene, 64, 64, 2, bvh=abi.BVH_SAH_REFINE | abi.BVH_WIDE, tracer=abi.TRACER_WAVEFRONT)
     ref_img, ref_ids, _ = orc.render(scene, ps, 64, 64, flags=orc.TRAVERSE_FAST)
     assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32)) and np.array_equal(ids, ref_ids)
+
+
+def test_wide_limit_is_an_error_and_pairs_still_work():
+    """Maximum sizes: 2^24 + 1 triangles are beyond the 8-wide format (24-bit node indices): crt_bvh_build says so, the
+    pair format builds and both tracers agree on it."""
+    n = (1 << 24) + 1
+    rs = np.random.RandomState(5)
+    tris = np.zeros(n, abi.tri_dtype)
+    c = rs.uniform(-50, 50, (n, 3)).astype(np.float32)
+    tris["v0"] = c
+    tris["v1"] = c + np.float32([0.3, 0.0, 0.0])
+    tris["v2"] = c + np.float32([0.0, 0.3, 0.1])
+    base = abi.builtin_scene("quads", 64, 64)
+    mats = base.materials[:1].copy()
+    params = base.params.copy()
+    params["camera"] = abi.camera((0, 0, 120), (0, 0, 0), 40.0, 1.0, 0.0, 10.0)
+    scene = abi.HostScene(tris=tris, materials=mats, params=params, name="many")
+    out = []
+    with abi.Context(0) as c0:
+        c0.configure(64, 64)
+        c0.upload(scene)
+        with pytest.raises(abi.CrtError, match="2\\^24"):
+            c0.build(abi.BVH_LBVH | abi.BVH_WIDE)
+        for tracer in (abi.TRACER_MEGAKERNEL, abi.TRACER_WAVEFRONT):
+            img, ids, _ = _gpu_render(c0, scene, 64, 64, 1, bvh=abi.BVH_LBVH, tracer=tracer)
+            out.append((img.view(np.uint32), ids))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert (out[0][1] != abi.ID_MISS).mean() > 0.5
