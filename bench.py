@@ -47,18 +47,29 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PMC_JSON = os.path.join(ROOT, "profiles", "r01_pmc.json")   # tools/pmc_to_json.py over the rocprofv3 --pmc passes of this command
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (a separate rocprofv3 --pmc run of this
-    same command: counters cannot be read from inside the benchmark), or None."""
+def pmc_counters(kernel_prefix):
+    """What the committed PMC passes say about the dominant kernel (a separate rocprofv3 --pmc run of this same command:
+    counters cannot be read from inside the benchmark), per launch: HBM-side bytes, VALU issue utilisation
+    (SQ_INSTS_VALU / (1024 SIMDs x quad-cycles of the launch)), live lanes per issued VALU instruction, resident waves
+    per SIMD and L2 hit rate.  {} when the file is missing."""
     try:
         ks = json.load(open(PMC_JSON))["kernels"]
     except (OSError, ValueError, KeyError):
-        return None
+        return {}
     best = None
     for name, d in ks.items():
         if kernel_prefix in name and "hbm_traffic_bytes_per_dispatch" in d and (best is None or d["dispatches"] > best["dispatches"]):
             best = d
-    return None if best is None else best["hbm_traffic_bytes_per_dispatch"]
+    if best is None:
+        return {}
+    out = {"traffic": best["hbm_traffic_bytes_per_dispatch"], "l2_hit_rate": best.get("l2_hit_rate")}
+    c = best.get("counters_per_dispatch", {})
+    cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0            # summed over the 8 XCDs
+    if cyc > 0 and c.get("SQ_INSTS_VALU"):
+        out["valu_issue_frac"] = round(c["SQ_INSTS_VALU"] / (1024.0 * cyc / 4.0), 3)
+        out["valu_lanes_live_frac"] = round(c.get("SQ_THREAD_CYCLES_VALU", 0.0) / c["SQ_INSTS_VALU"] / 64.0, 3)
+        out["waves_per_simd"] = round(c.get("SQ_WAVE_CYCLES", 0.0) * 4.0 / cyc / 1024.0, 2)
+    return out
 
 
 def parity_sample(scene, tracer, bvh_flags, device):
@@ -260,11 +271,15 @@ def main():
                        "rays_per_path": round(D, 3), "nodes_per_ray": round(V, 2), "prim_tests_per_ray": round(T, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": pmc_traffic("k_wf_extend" if kernel_name == "k_wf_extend" else "k_megakernel") if args.workload == "lost_empire_4k" and world == 1 else None,
+                         "traffic": None,
                          "kernel": kernel_name, "kernel_bytes_per_ray": round(kernel_bytes_per_ray, 1),
                          "pipeline_bytes_per_ray": round(bytes_per_ray, 1), "launch_ms": round(launch_ms, 4),
                          "launches": int(n_launches), "rays_per_launch": round(launch_rays)},
         }
+        if args.workload == "lost_empire_4k" and world == 1 and scene_name == "voxel_city":
+            pmc = pmc_counters("k_wf_extend<false" if kernel_name == "k_wf_extend" else "k_megakernel")
+            line["roofline"]["traffic"] = pmc.pop("traffic", None)
+            line["roofline"]["counters"] = dict(pmc, source="profiles/r01_pmc.json (rocprofv3 --pmc passes of this command)")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene)
             line["parity"] = parity_sample(scene, tracer, bvh_flags, local_rank)
