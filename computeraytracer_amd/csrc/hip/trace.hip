@@ -259,6 +259,7 @@ __device__ __forceinline__ uint32_t home_shard(uint32_t block, uint32_t wave, ui
 // prefix popcount), so lanes do not wait for the slowest ray of a batch.  Every wave reaches the exit: the pool can
 // only be refilled from cursors that grow monotonically up to fixed sizes.
 constexpr uint32_t kRefillLanes = 16;
+constexpr uint32_t kLeafLanes = 24;      // lanes waiting at a leaf that trigger a leaf-test phase (swept 8..32 on four workloads)
 
 // Per-lane traversal state behind one interface, so that k_wf_extend is written once for both node formats.  The
 // overflow ("spill") part of the stack is a separate local array handed in by pointer: inside the struct its dynamic
@@ -531,7 +532,7 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     q.n_shards = env_shards;
     static const uint32_t env_refill = [] { const char *e = getenv("CRT_WF_REFILL"); int v = e ? atoi(e) : (int)kRefillLanes; return (uint32_t)(v < 1 ? 1 : v > 64 ? 64 : v); }();
     q.refill = env_refill;
-    static const uint32_t env_leaf = [] { const char *e = getenv("CRT_WF_LEAF_LANES"); int v = e ? atoi(e) : 16; return (uint32_t)(v < 1 ? 1 : v > 64 ? 64 : v); }();
+    static const uint32_t env_leaf = [] { const char *e = getenv("CRT_WF_LEAF_LANES"); int v = e ? atoi(e) : (int)kLeafLanes; return (uint32_t)(v < 1 ? 1 : v > 64 ? 64 : v); }();
     q.leaf_lanes = env_leaf;
     q.tiles_per_shard = (n_vt + q.n_shards - 1) / q.n_shards;
     q.shard_cap = q.tiles_per_shard * 64;
@@ -630,7 +631,7 @@ bool launch_ray_query(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     WfQueues q;
     const uint32_t n_tiles = (n_rays + 63) / 64;
     q.n_shards = n_tiles >= 64 * 16 ? 64 : 1;                    // sub-queues only pay once every wave can have its own chunks
-    q.refill = kRefillLanes; q.leaf_lanes = 16;
+    q.refill = kRefillLanes; q.leaf_lanes = kLeafLanes;
     q.tiles_per_shard = (n_tiles + q.n_shards - 1) / q.n_shards;
     q.shard_cap = q.tiles_per_shard * 64;
     const size_t cap = (size_t)q.shard_cap * q.n_shards;
