@@ -28,6 +28,67 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+
+def launcher_plan(argv, n_gpus, port, base_env=None):
+    """What `python bench.py --gpus N` (N > 1, not already under a launcher) starts: one child per GPU, the same script and
+    arguments, with the torch.distributed.run environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns a list of
+    (argv, env) pairs; kept separate from the spawning so that a CPU test can check it for N = 8."""
+    env0 = dict(os.environ if base_env is None else base_env)
+    plan = []
+    for r in range(n_gpus):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+        plan.append(([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env))
+    return plan
+
+
+def requested_gpus(argv):
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    return n
+
+
+def launch_ranks(argv, n_gpus):
+    """Parent of a self-launched multi-GPU run.  It never touches the GPU (no torch, no libcrt.so: nothing has been
+    imported yet), starts the ranks as child processes, waits, and fails if any of them did.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [subprocess.Popen(a, env=e) for a, e in launcher_plan(argv, n_gpus, port)]
+    deadline = time.time() + float(os.environ.get("CRT_BENCH_LAUNCH_TIMEOUT", "1500"))
+    codes = [None] * n_gpus
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed or time.time() > deadline:      # one rank died (or the run hangs): the others would wait in a collective forever
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.kill()                        # exactly the PIDs started above
+                    codes[i] = p.wait()
+            break
+        time.sleep(0.05)
+    bad = [(i, c) for i, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and requested_gpus(sys.argv[1:]) > 1:
+    # `python bench.py --gpus N` on its own: become the launcher before anything GPU-related is imported
+    sys.exit(launch_ranks(sys.argv[1:], requested_gpus(sys.argv[1:])))
+
 if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("CRT_BENCH_FORCE_DIST", "") == "1":
     # PyTorch-ROCm bundles its own HIP runtime (same soname as /opt/rocm's).  Loaded first, libcrt.so binds to that one
     # copy; loaded second, the process ends up with two runtimes and the second cannot open the GPU.
@@ -137,6 +198,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        # --gpus N is honoured by the self-launcher above (no WORLD_SIZE in the environment) or must agree with the
+        # launcher that started this rank (torch.distributed.run --nproc-per-node N); never silently ignored
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; start it as `python bench.py --gpus {args.gpus}` "
+                         f"or under torch.distributed.run with --nproc-per-node {args.gpus}")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     # CRT_BENCH_REHEARSE=1: every rank on GPU 0 and gloo instead of RCCL, to rehearse the multi-rank path of this script

@@ -91,6 +91,7 @@ def _load():
         "crt_bvh_build": (i32, [vp, u32, P(f32)]),
         "crt_tris_update": (i32, [vp, vp, u32, u32]),
         "crt_tris_animate": (i32, [vp, f32, f32]),
+        "crt_tris_read": (i32, [vp, vp, u32, u32]),
         "crt_dispatch": (i32, [vp, vp]),
         "crt_render": (i32, [vp, vp, u32, u32, vp]),
         "crt_rays_query": (i32, [vp, vp, u32, u32, vp]),
@@ -306,6 +307,16 @@ class Context:
 
     def animate(self, frame, amplitude):
         self._check(lib.crt_tris_animate(self._h, frame, amplitude), "crt_tris_animate")
+
+    def tris_update(self, tris, first=0):
+        t = np.ascontiguousarray(tris, dtype=tri_dtype)
+        self._check(lib.crt_tris_update(self._h, _ptr(t), first, len(t)), "crt_tris_update")
+
+    def tris_read(self, first=0, count=None):
+        n = len(self._scene.tris) - first if count is None else count
+        out = np.zeros(n, dtype=tri_dtype)
+        self._check(lib.crt_tris_read(self._h, _ptr(out), first, n), "crt_tris_read")
+        return out
 
     def dispatch(self, params):
         p = np.ascontiguousarray(params, dtype=params_dtype)

@@ -34,10 +34,13 @@ struct BuildState {
     DeviceBuffer wide, wide_queue[2], wide_levels_dev;
     DeviceBuffer refit_list[2], refit_count[2];      // parked climbers between the stages of the LBVH refit
     uint32_t n_wide = 0, wide_levels = 0;
+    uint32_t pair_depth = 0;                         // levels of the SAH-refined pair tree (0: not measured, LBVH <= 95)
 };
 
 constexpr uint32_t kWideStrideF4 = 8;     // 128-byte node stride: the 64 bytes a step loads never straddle a line
 constexpr uint32_t kWideMaxLevels = 64;
+constexpr uint32_t kMaxPairDepth = 96;    // pair trees deeper than this are refused: a walk pushes at most depth - 1 entries and the
+                                          // stacks hold at least 1 (LDS, debug minimum) + 96 (scratch), intersect.h
 
 bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildState &st, std::string &err);
 bool build_sah(hipStream_t stream, const BuildInput &in, BuildState &st, const uint32_t *vals, std::string &err);
@@ -95,5 +98,6 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sc, const Frame
 bool launch_ray_query(hipStream_t stream, const DeviceSceneHost &sc, const FrameSetup &fs, WavefrontState &wf, const crt_ray *rays,
                       uint32_t n_rays, uint32_t mode, crt_ray_hit *hits, DeviceStats *stats, std::string &err);
 void free_wavefront(WavefrontState &wf);
+size_t wavefront_bytes(const WavefrontState &wf);      // device memory the tracer's queues hold right now
 
 }  // namespace crt

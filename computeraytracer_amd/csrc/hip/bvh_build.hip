@@ -411,14 +411,16 @@ __global__ void k_single_pair(const uint32_t *vals, const float4 *plo, const flo
     pairs[3] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(CRT_ID_KIND_TRI << 28));
 }
 
-// Config 5 animation: y = rest_y + amplitude * sin(frame + x + z) on every triangle vertex.
+// Config 5 animation: y = rest_y + amplitude * sin(frame + x + z) on every triangle vertex (SURVEY 8(d) config 5).
+// sinf is OCML's accurate single-precision sine (full argument reduction), not the __sinf hardware approximation: the
+// result feeds the BVH build and the tracer, and tests/test_gpu_parity.py checks it against float64 sin to 2 ulp.
 __global__ void k_animate_tris(uint32_t n, const crt_tri *rest, crt_tri *out, float frame, float amplitude) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     crt_tri t = rest[i];
-    t.v0[1] = t.v0[1] + amplitude * __sinf(frame + t.v0[0] + t.v0[2]);
-    t.v1[1] = t.v1[1] + amplitude * __sinf(frame + t.v1[0] + t.v1[2]);
-    t.v2[1] = t.v2[1] + amplitude * __sinf(frame + t.v2[0] + t.v2[2]);
+    t.v0[1] = t.v0[1] + amplitude * sinf((frame + t.v0[0]) + t.v0[2]);
+    t.v1[1] = t.v1[1] + amplitude * sinf((frame + t.v1[0]) + t.v1[2]);
+    t.v2[1] = t.v2[1] + amplitude * sinf((frame + t.v2[0]) + t.v2[2]);
     out[i] = t;
 }
 

@@ -20,6 +20,7 @@
 // Everything is deterministic (integer atomics on encoded floats, stable partitions).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -209,7 +210,10 @@ __device__ void sah_wave_subtree(const SahGroupArgs &g, SahLds &L, uint32_t grou
         bool leaf = false;
         const uint32_t kind0 = (uint32_t)__shfl((int)kind, (int)s0);
         const unsigned long long mism = __ballot(open && kind != kind0);
-        if (g.level0 && open && len <= g.max_leaf) {
+        // The root of the whole tree is never closed as a leaf: it has no descriptor slot (put_desc drops it), and pair 0
+        // would keep its all-zero memset, i.e. two "inner" children linking back to pair 0.  It always splits into pair 0.
+        const bool tree_root = (y & kEntRoot) != 0u && g.desc_out == nullptr;
+        if (g.level0 && open && len <= g.max_leaf && !tree_root) {
             const unsigned long long seg = (len >= 64u ? ~0ull : (1ull << len) - 1ull) << s0;
             const float area = half_area3(nlo, nhi);
             leaf = (mism & seg) == 0ull && g.c_isect * (float)len * area <= g.c_trav * area + g.c_isect * split_cost;
@@ -467,10 +471,48 @@ bool build_sah(hipStream_t stream, const BuildInput &in, BuildState &st, const u
     return true;
 }
 
+// Depth of the rebuilt pair tree.  The Karras LBVH is at most 95 levels deep (63 Morton bits + 32 index bits), which is
+// what the traversal stacks are sized for (intersect.h: kLdsStack + kSpillStack); the SAH rebuild has no such bound (a
+// sweep can peel one item per level, in every tier), so it is measured and the build refuses a tree the pair tracers
+// could not walk.  parent[] of a pair = the pair that links to it (a real inner child never links to pair 0: the root
+// is nobody's child, so link 0 marks the holes left by multi-primitive leaves).
+__global__ void k_pair_parents(uint32_t n_halves, const float4 *pairs, uint32_t *parent) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_halves) return;
+    const uint32_t count = __float_as_uint(pairs[2 * (size_t)h + 1].w), link = __float_as_uint(pairs[2 * (size_t)h].w);
+    if (count == 0u && link != 0u && link < n_halves / 2u) parent[link] = h >> 1;
+}
+__global__ void k_pair_depth(uint32_t n_pairs, const uint32_t *parent, uint32_t *max_depth) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t d = 0;
+    if (p < n_pairs) {
+        d = 1;
+        for (uint32_t q = parent[p]; q != 0xFFFFFFFFu && d <= n_pairs; q = parent[q]) d++;      // d <= n_pairs: a corrupt table cannot hang the kernel
+    }
+    for (int off = 32; off > 0; off >>= 1) d = max(d, (uint32_t)__shfl_xor((int)d, off));
+    if ((threadIdx.x & 63u) == 0u && d) atomicMax(max_depth, d);
+}
+
 bool patch_sah_links(hipStream_t stream, BuildState &st, std::string &err) {
     const uint32_t halves = 2 * st.n_pairs;
     hipLaunchKernelGGL(k_sah_patch_links, dim3((halves + 255) / 256), dim3(256), 0, stream, halves, (float4 *)st.pairs.ptr, (const uint32_t *)st.leaf_link.ptr);
+    // st.parent (the LBVH's parent table, 2n words) is free again after build_sah; word 8 of scene_bounds holds the result
+    uint32_t *parent = (uint32_t *)st.parent.ptr, *depth_dev = (uint32_t *)st.scene_bounds.ptr + 8;
+    HIP_TRY(hipMemsetAsync(parent, 0xFF, (size_t)st.n_pairs * 4, stream));
+    HIP_TRY(hipMemsetAsync(depth_dev, 0, 4, stream));
+    hipLaunchKernelGGL(k_pair_parents, dim3((halves + 255) / 256), dim3(256), 0, stream, halves, (const float4 *)st.pairs.ptr, parent);
+    hipLaunchKernelGGL(k_pair_depth, dim3((st.n_pairs + 255) / 256), dim3(256), 0, stream, st.n_pairs, (const uint32_t *)parent, depth_dev);
     HIP_TRY(hipGetLastError());
+    uint32_t depth = 0;
+    HIP_TRY(hipMemcpyAsync(&depth, depth_dev, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    st.pair_depth = depth;
+    uint32_t limit = kMaxPairDepth;
+    if (const char *e = getenv("CRT_BVH_MAX_PAIR_DEPTH")) { const int v = atoi(e); if (v >= 1 && (uint32_t)v < limit) limit = (uint32_t)v; }   // test hook: can only lower it
+    if (depth > limit) {
+        err = "SAH-refined tree is " + std::to_string(depth) + " levels deep; the pair traversal stacks hold " + std::to_string(limit);
+        return false;
+    }
     return true;
 }
 

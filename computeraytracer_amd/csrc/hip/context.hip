@@ -16,10 +16,14 @@ using namespace crt;
 struct crt_context {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // Two timing slots, like the reference's two frame slots with a fence each (vk_engine.h:18, vk_engine.cpp:1377):
+    // dispatch i records into slot i % 2 and only waits if the dispatch two calls back has not finished yet.
+    struct TimingSlot { hipEvent_t start = nullptr, stop = nullptr; bool pending = false; } slot[2];
+    uint32_t slot_next = 0;
+    hipEvent_t ev_build[2] = {nullptr, nullptr};
     std::string error;
     crt_config cfg{};
-    bool configured = false, have_scene = false, have_bvh = false, timing_pending = false;
+    bool configured = false, have_scene = false, have_bvh = false;
     // scene (reference layouts, input order)
     DeviceBuffer spheres, quads, tris, tris_rest, materials, tex0, dbg_boxes;
     uint32_t n_dbg_boxes = 0;
@@ -97,20 +101,52 @@ FrameSetup frame_setup(const crt_context *ctx) {
     return fs;
 }
 
-int finish_timing(crt_context *ctx) {
-    if (!ctx->timing_pending) return CRT_OK;
-    CTX_HIP(hipEventSynchronize(ctx->ev_stop));
+// Reads the device time of a finished dispatch out of its slot.  block = false: only if it has already finished.
+int harvest_slot(crt_context *ctx, crt_context::TimingSlot &sl, bool block) {
+    if (!sl.pending) return CRT_OK;
+    if (!block) {
+        const hipError_t q = hipEventQuery(sl.stop);
+        if (q == hipErrorNotReady) return CRT_OK;
+        if (q != hipSuccess) return fail(ctx, CRT_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+    } else CTX_HIP(hipEventSynchronize(sl.stop));
     float ms = 0.0f;
-    CTX_HIP(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    CTX_HIP(hipEventElapsedTime(&ms, sl.start, sl.stop));
     ctx->last_render_ms = ms;
-    ctx->timing_pending = false;
-    ctx->last_extend_ms = 0.0; ctx->last_extend_launches = ctx->wf.ev_used / 2;
-    for (size_t i = 0; i + 1 < ctx->wf.ev_used; i += 2) {
-        float e = 0.0f;
-        CTX_HIP(hipEventElapsedTime(&e, ctx->wf.ev[i], ctx->wf.ev[i + 1]));
-        ctx->last_extend_ms += e;
+    sl.pending = false;
+    return CRT_OK;
+}
+
+// Blocking: every dispatch issued so far has its time read (older slot first, so last_render_ms is the newest) and,
+// with crt_set_kernel_timing on, the k_wf_extend events are summed.
+int finish_timing(crt_context *ctx) {
+    for (uint32_t k = 0; k < 2; k++) {
+        int rc = harvest_slot(ctx, ctx->slot[(ctx->slot_next + k) & 1u], true);
+        if (rc) return rc;
     }
-    ctx->wf.ev_used = 0;
+    if (ctx->wf.ev_used) {
+        ctx->last_extend_ms = 0.0; ctx->last_extend_launches = ctx->wf.ev_used / 2;
+        for (size_t i = 0; i + 1 < ctx->wf.ev_used; i += 2) {
+            float e = 0.0f;
+            CTX_HIP(hipEventElapsedTime(&e, ctx->wf.ev[i], ctx->wf.ev[i + 1]));
+            ctx->last_extend_ms += e;
+        }
+        ctx->wf.ev_used = 0;
+    }
+    return CRT_OK;
+}
+
+// Start of a dispatch: takes the next timing slot.  crt_dispatch / crt_render stay asynchronous (abi.h): the call waits
+// only when the dispatch TWO calls back is still running (the reference's waitForFences on its frame slot), or when
+// per-kernel timing was asked for (crt_set_kernel_timing: one set of k_wf_extend events, read before it is reused).
+int begin_timing(crt_context *ctx, crt_context::TimingSlot **out) {
+    int rc;
+    if (ctx->wf.time_kernels && (rc = finish_timing(ctx))) return rc;
+    crt_context::TimingSlot &sl = ctx->slot[ctx->slot_next];
+    if ((rc = harvest_slot(ctx, sl, true))) return rc;                                   // the dispatch two calls back
+    if ((rc = harvest_slot(ctx, ctx->slot[ctx->slot_next ^ 1u], false))) return rc;      // the previous one, if it is done already
+    ctx->slot_next ^= 1u;
+    CTX_HIP(hipEventRecord(sl.start, ctx->stream));
+    *out = &sl;
     return CRT_OK;
 }
 
@@ -153,7 +189,9 @@ int crt_create(int device, crt_context **out) {
     crt_context *ctx = new crt_context();
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+        hipEventCreate(&ctx->slot[0].start) != hipSuccess || hipEventCreate(&ctx->slot[0].stop) != hipSuccess ||
+        hipEventCreate(&ctx->slot[1].start) != hipSuccess || hipEventCreate(&ctx->slot[1].stop) != hipSuccess ||
+        hipEventCreate(&ctx->ev_build[0]) != hipSuccess || hipEventCreate(&ctx->ev_build[1]) != hipSuccess) {
         delete ctx;
         return CRT_ERR_HIP;
     }
@@ -171,7 +209,8 @@ void crt_destroy(crt_context *ctx) {
         for (DeviceBuffer *b : all) release(*b);
         free_build_state(ctx->build);
         free_wavefront(ctx->wf);
-        e = hipEventDestroy(ctx->ev_start); e = hipEventDestroy(ctx->ev_stop); e = hipStreamDestroy(ctx->stream); (void)e;
+        for (auto &sl : ctx->slot) { e = hipEventDestroy(sl.start); e = hipEventDestroy(sl.stop); }
+        e = hipEventDestroy(ctx->ev_build[0]); e = hipEventDestroy(ctx->ev_build[1]); e = hipStreamDestroy(ctx->stream); (void)e;
     }
     delete ctx;
 }
@@ -185,6 +224,13 @@ int crt_configure(crt_context *ctx, const crt_config *cfg) {
     if (cfg->rng_mode > CRT_RNG_PCG || cfg->tracer > CRT_TRACER_WAVEFRONT) return fail(ctx, CRT_ERR_INVALID, "crt_configure: unknown rng_mode/tracer");
     if (cfg->band_world > 1 && cfg->band_rank >= cfg->band_world) return fail(ctx, CRT_ERR_INVALID, "crt_configure: band_rank >= band_world");
     CTX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->configured && (cfg->width != ctx->cfg.width || cfg->height != ctx->cfg.height || cfg->band_world != ctx->cfg.band_world ||
+                            cfg->band_rank != ctx->cfg.band_rank || cfg->tracer != ctx->cfg.tracer)) {
+        // a different frame: the wavefront queues (up to ~16 GB for a full batch) are sized again by the next render,
+        // so a context reconfigured to a smaller image does not keep the large frame's buffers
+        if ((rc = finish_timing(ctx))) return rc;
+        free_wavefront(ctx->wf);
+    }
     ctx->cfg = *cfg;
     bool full = (cfg->flags & CRT_FLAG_FULL_IMAGE) != 0;
     ctx->grid_w = full ? cfg->width : (cfg->width / 8) * 8;      // dispatch(W/8, H/8, 1), vk_engine.cpp:1435
@@ -248,17 +294,15 @@ int crt_bvh_build(crt_context *ctx, uint32_t flags, float *build_ms) {
     if (const char *e = getenv("CRT_BVH_MAX_LEAF")) ctx->build.max_leaf = (uint32_t)atoi(e);      // experiment knobs
     if (const char *e = getenv("CRT_BVH_CI")) ctx->build.c_isect = (float)atof(e);
     if (const char *e = getenv("CRT_BVH_CT")) ctx->build.c_trav = (float)atof(e);
-    hipEvent_t e0, e1;
-    CTX_HIP(hipEventCreate(&e0)); CTX_HIP(hipEventCreate(&e1));
-    // warm the allocations (first build at a size allocates; the timed region below then only launches)
+    hipEvent_t e0 = ctx->ev_build[0], e1 = ctx->ev_build[1];      // owned by the context: no event is created (or leaked) per build
+    ctx->have_bvh = false;
     CTX_HIP(hipEventRecord(e0, ctx->stream));
     bool ok = build_bvh(ctx->stream, in, flags, ctx->build, err);
     CTX_HIP(hipEventRecord(e1, ctx->stream));
-    if (!ok) { hipError_t e = hipEventDestroy(e0); e = hipEventDestroy(e1); (void)e; return fail(ctx, CRT_ERR_HIP, "crt_bvh_build: " + err); }
+    if (!ok) return fail(ctx, CRT_ERR_HIP, "crt_bvh_build: " + err);
     CTX_HIP(hipEventSynchronize(e1));
     float ms = 0.0f;
     CTX_HIP(hipEventElapsedTime(&ms, e0, e1));
-    CTX_HIP(hipEventDestroy(e0)); CTX_HIP(hipEventDestroy(e1));
     ctx->last_build_ms = ms;
     if (build_ms) *build_ms = ms;
     ctx->have_bvh = true;
@@ -271,7 +315,19 @@ int crt_tris_update(crt_context *ctx, const crt_tri *tris, uint32_t first, uint3
     if (!tris || (uint64_t)first + count > ctx->n_tris) return fail(ctx, CRT_ERR_INVALID, "crt_tris_update: range outside the uploaded triangles");
     CTX_HIP(hipStreamSynchronize(ctx->stream));
     CTX_HIP(hipMemcpy((crt_tri *)ctx->tris.ptr + first, tris, (size_t)count * sizeof(crt_tri), hipMemcpyDefault));
+    // after crt_tris_animate the rest pose is a second copy: the update replaces the triangles there too, so the next
+    // crt_tris_animate displaces the NEW vertices instead of silently restoring the old ones
+    if (ctx->animated) CTX_HIP(hipMemcpy((crt_tri *)ctx->tris_rest.ptr + first, tris, (size_t)count * sizeof(crt_tri), hipMemcpyDefault));
     ctx->have_bvh = false;
+    return CRT_OK;
+}
+
+int crt_tris_read(crt_context *ctx, crt_tri *tris, uint32_t first, uint32_t count) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!ctx->have_scene) return fail(ctx, CRT_ERR_INVALID, "crt_tris_read: no scene uploaded");
+    if ((count && !tris) || (uint64_t)first + count > ctx->n_tris) return fail(ctx, CRT_ERR_INVALID, "crt_tris_read: range outside the uploaded triangles");
+    CTX_HIP(hipStreamSynchronize(ctx->stream));
+    if (count) CTX_HIP(hipMemcpy(tris, (const crt_tri *)ctx->tris.ptr + first, (size_t)count * sizeof(crt_tri), hipMemcpyDefault));
     return CRT_OK;
 }
 
@@ -295,11 +351,11 @@ int crt_dispatch(crt_context *ctx, const crt_scene_params *params) {
     int rc = bind(ctx); if (rc) return rc;
     if (!params) return fail(ctx, CRT_ERR_INVALID, "crt_dispatch: null params");
     if ((rc = ready_to_render(ctx))) return rc;
-    if ((rc = finish_timing(ctx))) return rc;
-    CTX_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
+    crt_context::TimingSlot *sl = nullptr;
+    if ((rc = begin_timing(ctx, &sl))) return rc;
     rc = dispatch_one(ctx, *params);
-    CTX_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
-    ctx->timing_pending = true;
+    CTX_HIP(hipEventRecord(sl->stop, ctx->stream));
+    sl->pending = true;
     return rc;
 }
 
@@ -307,8 +363,8 @@ int crt_render(crt_context *ctx, const crt_scene_params *params, uint32_t first_
     int rc = bind(ctx); if (rc) return rc;
     if (!params || (n_iterations && !seeds)) return fail(ctx, CRT_ERR_INVALID, "crt_render: null params/seeds");
     if ((rc = ready_to_render(ctx))) return rc;
-    if ((rc = finish_timing(ctx))) return rc;
-    CTX_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
+    crt_context::TimingSlot *sl = nullptr;
+    if ((rc = begin_timing(ctx, &sl))) return rc;
     crt_scene_params p = *params;
     // The wavefront tracer traces several iterations of a small frame together (their paths share the queues, the
     // accumulation still happens in iteration order, so the image is bit-identical): a launch needs a few million
@@ -319,6 +375,13 @@ int crt_render(crt_context *ctx, const crt_scene_params *params, uint32_t first_
         const double per_iter = (double)ctx->n_local_bands * 8.0 * ctx->grid_w;
         batch = per_iter > 0.0 ? (uint32_t)(target / per_iter) : 1u;
         batch = batch < 1u ? 1u : batch > 64u ? 64u : batch;
+        // ... and by memory: a batch of b iterations holds 104 B of queues + hit record per path slot and 16 B of radiance
+        // per pixel and iteration.  At most half of what is free now plus what the tracer already holds.
+        size_t free_b = 0, total_b = 0;
+        CTX_HIP(hipMemGetInfo(&free_b, &total_b));
+        const double budget = 0.5 * ((double)free_b + (double)wavefront_bytes(ctx->wf));
+        const double per_b = ((double)ctx->n_local_bands * 8.0 * (((double)ctx->grid_w + 7.0) / 8.0) * 8.0) * 104.0 + (double)ctx->local_rows * ctx->cfg.width * 16.0;
+        if (per_b > 0.0 && batch * per_b > budget) batch = (uint32_t)(budget / per_b) < 1u ? 1u : (uint32_t)(budget / per_b);
         if ((size_t)ctx->local_rows * ctx->cfg.width >= (1u << 26) - 1u) batch = 1;      // ray_d.w packs batch index << 26 | pixel slot
     }
     for (uint32_t i = 0; i < n_iterations && rc == CRT_OK; i += batch) {
@@ -327,8 +390,8 @@ int crt_render(crt_context *ctx, const crt_scene_params *params, uint32_t first_
         p.camera.seed = seeds[i];
         rc = dispatch_one(ctx, p, nb, seeds + i);
     }
-    CTX_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
-    ctx->timing_pending = true;
+    CTX_HIP(hipEventRecord(sl->stop, ctx->stream));
+    sl->pending = true;
     return rc;
 }
 

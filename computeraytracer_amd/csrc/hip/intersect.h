@@ -37,7 +37,8 @@ struct DeviceScene {
 #define CRT_LDS_STACK 24
 #endif
 constexpr int kLdsStack = CRT_LDS_STACK;     // per-lane LDS stack entries; deeper levels spill to scratch
-constexpr int kSpillStack = 96;               // pair trees are at most 95 deep (63 Morton bits + 32 index bits); lds_depth may be as low as 1
+constexpr int kSpillStack = 96;               // LBVH pair trees are at most 95 deep (63 Morton bits + 32 index bits); SAH-refined ones are measured at
+                                              // build time and refused beyond kMaxPairDepth = 96 (bvh_sah.hip); lds_depth may be as low as 1
 constexpr uint32_t kIdMiss = 0xFFFFFFFFu;
 
 CRT_DEV bool accept_hit(float t, uint32_t id, float best_t, uint32_t best_id) {

@@ -673,6 +673,13 @@ bool launch_ray_query(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     return true;
 }
 
+size_t wavefront_bytes(const WavefrontState &wf) {
+    const DeviceBuffer *all[] = {&wf.ray_o[0], &wf.ray_o[1], &wf.ray_d[0], &wf.ray_d[1], &wf.thr[0], &wf.thr[1], &wf.hit, &wf.counters, &wf.pass, &wf.query_rays};
+    size_t n = 0;
+    for (const DeviceBuffer *b : all) n += b->bytes;
+    return n;
+}
+
 void free_wavefront(WavefrontState &wf) {
     DeviceBuffer *all[] = {&wf.ray_o[0], &wf.ray_o[1], &wf.ray_d[0], &wf.ray_d[1], &wf.thr[0], &wf.thr[1],
                            &wf.hit, &wf.counters, &wf.pass, &wf.query_rays};

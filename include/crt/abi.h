@@ -72,9 +72,12 @@ int crt_bvh_build(crt_context *ctx, uint32_t flags, float *build_ms);
  * device-resident or host memory, then call crt_bvh_build again.  No
  * counterpart in the reference (its BVHs are built once: vk_engine.cpp:748-934). */
 int crt_tris_update(crt_context *ctx, const crt_tri *tris, uint32_t first, uint32_t count);
+/* Reads triangles [first, first + count) back as they are on the device now (after crt_tris_animate / crt_tris_update)
+ * into host or device memory.  Synchronous.  Build-only diagnostic: the parity tests hand these triangles to the oracle. */
+int crt_tris_read(crt_context *ctx, crt_tri *tris, uint32_t first, uint32_t count);
 /* Device-side animation used by the 10M-triangle benchmark: displaces every
  * triangle vertex's y by amplitude * sin(frame + x + z) relative to the
- * uploaded rest pose. */
+ * rest pose (the triangles as uploaded, or as last replaced by crt_tris_update). */
 int crt_tris_animate(crt_context *ctx, float frame, float amplitude);
 
 /* Replaces one frame of VulkanEngine::draw (vk_engine.cpp:1409-1435): the
@@ -91,6 +94,13 @@ int crt_dispatch(crt_context *ctx, const crt_scene_params *params);
  * grows with the batch (136 bytes per path). */
 int crt_render(crt_context *ctx, const crt_scene_params *params, uint32_t first_iteration,
                uint32_t n_iterations, const float *seeds);
+/* Device memory: scene + BVH (about 250 bytes per primitive including build scratch), the image (20 bytes per pixel)
+ * and, for the wavefront tracer, the queues of one batch: 104 bytes per path slot + 16 bytes per pixel and iteration of
+ * the batch.  A batch is capped at half of the memory that is free when crt_render is called (plus what the context's
+ * queues already hold), so several contexts on one GPU shrink each other's batches instead of failing; crt_configure
+ * to a different frame releases the queues.  crt_dispatch / crt_render return without waiting for the GPU: a call
+ * blocks only while the dispatch two calls back is still running (two timing slots, like the reference's two frame
+ * slots, vk_engine.cpp:1377) or when crt_set_kernel_timing is on. */
 
 /* Ray queries against the current scene and BVH: closest hit or any hit ("shadow ray") for n_rays caller-supplied
  * rays, the same hit_world the path tracer runs (compute.comp:326-361: same intersection arithmetic, same interval

@@ -209,4 +209,28 @@ typedef struct crt_stats {
 #ifdef __cplusplus
 }
 #endif
+
+/* Layout contract: sizes and the offsets the shader's std140/std430 blocks imply.  Checked
+ * in C11 and C++ alike, so a compiler that pads differently fails the build instead of the picture. */
+#include <stddef.h>
+#ifdef __cplusplus
+#define CRT_STATIC_ASSERT(c, m) static_assert(c, m)
+#else
+#define CRT_STATIC_ASSERT(c, m) _Static_assert(c, m)
+#endif
+CRT_STATIC_ASSERT(sizeof(crt_sphere) == 32 && offsetof(crt_sphere, radius) == 12 && offsetof(crt_sphere, materialIndex) == 28, "T3 Sphere::GPU_t");
+CRT_STATIC_ASSERT(sizeof(crt_quad) == 96 && offsetof(crt_quad, d) == 12 && offsetof(crt_quad, u) == 16 && offsetof(crt_quad, v) == 32 &&
+                  offsetof(crt_quad, normal) == 48 && offsetof(crt_quad, w) == 64 && offsetof(crt_quad, materialIndex) == 92, "T4 Quad::GPU_t");
+CRT_STATIC_ASSERT(sizeof(crt_tri) == 96 && offsetof(crt_tri, v1) == 16 && offsetof(crt_tri, v2) == 32 && offsetof(crt_tri, u) == 48 &&
+                  offsetof(crt_tri, v) == 64 && offsetof(crt_tri, materialIndex) == 92, "T2 Tri::GPU_t");
+CRT_STATIC_ASSERT(sizeof(crt_material) == 48 && offsetof(crt_material, fuzziness) == 12 && offsetof(crt_material, type) == 28 &&
+                  offsetof(crt_material, textureIndex) == 44, "T5 RTMaterial::GPU_t");
+CRT_STATIC_ASSERT(sizeof(crt_ref_bvh_node) == 64 && offsetof(crt_ref_bvh_node, aabb_max) == 16 && offsetof(crt_ref_bvh_node, objectIndex) == 32 &&
+                  offsetof(crt_ref_bvh_node, hitIndex) == 36 && offsetof(crt_ref_bvh_node, missIndex) == 40 && offsetof(crt_ref_bvh_node, type) == 48 &&
+                  offsetof(crt_ref_bvh_node, numChildren) == 52, "T1 BVHNode::GPU_t");
+CRT_STATIC_ASSERT(sizeof(crt_camera_data) == 96 && offsetof(crt_camera_data, shouldRenderAABB) == 12 && offsetof(crt_camera_data, lensRadius) == 28 &&
+                  offsetof(crt_camera_data, focusDistance) == 44 && offsetof(crt_camera_data, iteration) == 60 && offsetof(crt_camera_data, seed) == 76 &&
+                  offsetof(crt_camera_data, vertical) == 80, "T6 GPUCameraData");
+CRT_STATIC_ASSERT(sizeof(crt_scene_params) == 112 && offsetof(crt_scene_params, camera) == 16, "T6 GPUSceneData");
+CRT_STATIC_ASSERT(sizeof(crt_bvh_node) == 32 && sizeof(crt_ray) == 32 && sizeof(crt_ray_hit) == 8, "build-side PODs");
 #endif /* CRT_TYPES_H */

@@ -90,6 +90,9 @@ enum {
     ORC_RNG_PCG        = 1 << 4, // pcg32 instead of the shader hash
     ORC_FULL_IMAGE     = 1 << 5, // render W x H instead of floor(W/8)*8 x floor(H/8)*8
     ORC_LIBM           = 1 << 6, // libm transcendentals instead of the fixed polynomial sequences
+    // bits 8-15: band_world, bits 16-23: band_rank.  band_world > 1 renders only the 8-row bands b with
+    // b % band_world == band_rank (the multi-GPU partition); the other rows of accum / ids stay untouched.
+    ORC_BAND_WORLD_SHIFT = 8, ORC_BAND_RANK_SHIFT = 16,
 };
 
 // ------------------------------------------------------------------- vec3 ---
@@ -932,6 +935,8 @@ int orc_render(const orc_scene *scene, const orc_world_desc *world, const orc_bu
     uint32_t gw = (flags & ORC_FULL_IMAGE) ? W : (W / 8) * 8;    // dispatch(W/8, H/8, 1), vk_engine.cpp:1435
     uint32_t gh = (flags & ORC_FULL_IMAGE) ? H : (H / 8) * 8;
     const Params *ps = (const Params *)params;
+    const uint32_t band_world = ((uint32_t)flags >> ORC_BAND_WORLD_SHIFT) & 0xFFu, band_rank = ((uint32_t)flags >> ORC_BAND_RANK_SHIFT) & 0xFFu;
+    if (band_world > 1 && band_rank >= band_world) return -3;
     Counters total{};
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
@@ -942,6 +947,7 @@ int orc_render(const orc_scene *scene, const orc_world_desc *world, const orc_bu
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nv, pt, paths, bounces)
         for (int64_t y = 0; y < (int64_t)gh; y++) {
             Counters c{};
+            if (band_world > 1 && ((uint32_t)y / 8u) % band_world != band_rank) continue;
             for (uint32_t x = 0; x < gw; x++)
                 shade_pixel(w, p, W, H, x, (uint32_t)y, flags, max_bounces, accum, it + 1 == n_iter ? ids : nullptr, c);
             rays += c.rays; nv += c.node_visits; pt += c.prim_tests; paths += c.paths; bounces += c.bounces;
@@ -950,6 +956,40 @@ int orc_render(const orc_scene *scene, const orc_world_desc *world, const orc_bu
     }
     if (counters) { counters->rays = total.rays; counters->node_visits = total.node_visits; counters->prim_tests = total.prim_tests;
                     counters->paths = total.paths; counters->bounces = total.bounces; }
+    return 0;
+}
+
+/* Primary rays of ONE dispatch only (main() up to the first hit_world call, compute.comp:460-468 + :442): per pixel the
+ * distance and ID of the primary hit (t = +inf, ID_MISS where the camera ray hits nothing).  Used to measure how far
+ * apart the reference's first-tested-wins result and the canonical lowest-ID result are where they differ. */
+int orc_primary_hits(const orc_scene *scene, const orc_world_desc *world, const void *params, uint32_t W, uint32_t H, int flags,
+                     int threads, float *t_out, uint32_t *ids) {
+    World w;
+    world_init(w, to_scene(scene), flags);
+    if (w.traverse == ORC_TRAVERSE_REF) {
+        if (!world || world->n_objects == 0) return -1;
+        build_reference_bvh(w.sc, world->n_objects, world->obj_offsets, world->obj_prims, world->obj_is_list, w.ref);
+    }
+    if (w.traverse == ORC_TRAVERSE_BUILD) return -2;
+    g_libm = (flags & ORC_LIBM) != 0;
+    const Params &p = *(const Params *)params;
+    const uint32_t gw = (flags & ORC_FULL_IMAGE) ? W : (W / 8) * 8, gh = (flags & ORC_FULL_IMAGE) ? H : (H / 8) * 8;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t y = 0; y < (int64_t)gh; y++)
+        for (uint32_t x = 0; x < gw; x++) {
+            Rng rng{};
+            rng.seed = p.camera.seed * ((float)x * (float)y + (float)y * (float)x);
+            if (flags & ORC_RNG_PCG) pcg_seed(rng, (uint32_t)y * W + x, p.camera.seed, p.camera.iteration);
+            float off[2]; hash_2(rng, off);
+            const float u = ((float)x + off[0]) / (float)W, v = ((float)y + off[1]) / (float)H;
+            Hit rec{}; Counters c{};
+            const bool hit = hit_world(w, camera_get_ray(p.camera, u, v, rng), rec, c);
+            t_out[(size_t)y * W + x] = hit ? rec.t : INF_F;
+            ids[(size_t)y * W + x] = hit ? rec.id : ID_MISS;
+        }
     return 0;
 }
 

@@ -16,6 +16,11 @@ TRAVERSE_BRUTE, TRAVERSE_FAST, TRAVERSE_REF, TRAVERSE_BUILD = 0, 1, 2, 3
 RNG_PCG, FULL_IMAGE, LIBM = 1 << 4, 1 << 5, 1 << 6
 
 
+def BANDS(rank, world):
+    """Flag bits that restrict orc_render to the 8-row bands b with b % world == rank (world <= 255)."""
+    return (world << 8) | (rank << 16)
+
+
 class OrcScene(C.Structure):
     _fields_ = [("spheres", C.c_void_p), ("n_spheres", C.c_uint32), ("quads", C.c_void_p), ("n_quads", C.c_uint32),
                 ("tris", C.c_void_p), ("n_tris", C.c_uint32), ("materials", C.c_void_p), ("n_materials", C.c_uint32),
@@ -67,6 +72,8 @@ def _load():
     lib.orc_camera.argtypes = [vp, vp, f32, f32, f32, f32, vp]
     lib.orc_glibc_rand.argtypes = [u32, u32, vp]
     lib.orc_max_threads.restype = i32
+    lib.orc_primary_hits.restype = i32
+    lib.orc_primary_hits.argtypes = [C.POINTER(OrcScene), C.POINTER(OrcWorld), vp, u32, u32, i32, i32, vp, vp]
     lib.orc_hit_rays.restype = i32
     lib.orc_hit_rays.argtypes = [C.POINTER(OrcScene), i32, vp, u32, i32, vp]
     return lib
@@ -118,6 +125,39 @@ def render(scene, params_list, width, height, flags=TRAVERSE_FAST, max_bounces=0
     if rc != 0:
         raise RuntimeError(f"orc_render failed: {rc}")
     return accum, ids, cnt
+
+
+def primary_hits(scene, params, width, height, flags=TRAVERSE_FAST, threads=0):
+    """(t[h,w], ids[h,w]) of the primary rays of one dispatch."""
+    ref = SceneRef(scene)
+    p = np.ascontiguousarray(np.asarray(params).reshape(1))
+    t = np.full((height, width), np.inf, dtype=np.float32)
+    ids = np.full((height, width), 0xFFFFFFFF, dtype=np.uint32)
+    rc = lib.orc_primary_hits(C.byref(ref.s), C.byref(ref.w) if ref.w is not None else None, _p(p), width, height, flags, threads, _p(t), _p(ids))
+    if rc != 0:
+        raise RuntimeError(f"orc_primary_hits failed: {rc}")
+    return t, ids
+
+
+def tie_break_report(scene, params_list, width, height, threads=0):
+    """Reference order (threaded BVH + strict '<': the first primitive tested wins an exact tie in t, compute.comp:239,260,
+    301,358) against the canonical lowest-ID tie-break on the same scene and seeds.  Primary rays of every dispatch in
+    params_list: pixels whose primary-hit ID differs and the largest distance, in ulps of t, between the two hits at such
+    a pixel (at most 1e-5 of the pixels, each within 4 ulp)."""
+    mism, max_ulp, miss_flips = 0, 0, 0
+    for p in params_list:
+        t0, i0 = primary_hits(scene, p, width, height, TRAVERSE_FAST, threads)
+        t1, i1 = primary_hits(scene, p, width, height, TRAVERSE_REF, threads)
+        d = i0 != i1
+        mism += int(d.sum())
+        if d.any():
+            a, b = t0[d], t1[d]
+            fin = np.isfinite(a) & np.isfinite(b)
+            miss_flips += int((~fin).sum())               # hit on one side, miss on the other: never a tie
+            if fin.any():
+                max_ulp = max(max_ulp, int(np.abs(a[fin].view(np.int32).astype(np.int64) - b[fin].view(np.int32).astype(np.int64)).max()))
+    return {"primary_rays": int(width // 8 * 8) * int(height // 8 * 8) * len(params_list), "primary_id_mismatches": mism,
+            "max_ulp_between_mismatching_hits": max_ulp, "hit_vs_miss_mismatches": miss_flips}
 
 
 def hit_rays(scene, rays, flags=TRAVERSE_BRUTE, threads=0):

@@ -599,3 +599,198 @@ def test_wide_limit_is_an_error_and_pairs_still_work():
             out.append((img.view(np.uint32), ids))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert (out[0][1] != abi.ID_MISS).mean() > 0.5
+
+
+# ---- round 2: paths the first round's tests never reached --------------------------------------------------------
+
+def _tiny_scene(kind, w, h):
+    """2-4 primitives of one kind: with the SAH's default leaf size (4) the whole scene fits one leaf, which used to leave
+    pair 0 unwritten (the root closed as a leaf has no descriptor slot)."""
+    base = abi.builtin_scene("quads", w, h)
+    mats = base.materials[:2].copy()
+    params = base.params.copy()
+    params["camera"] = abi.camera((0.3, 0.2, 6.0), (0, 0, 0), 40.0, w / h, 0.0, 10.0)
+    if kind.startswith("tris"):
+        n = int(kind[4:])
+        # coplanar (z = 0), counter-clockwise seen from +z: single-sided triangles face the camera (compute.comp:290-296)
+        fan = np.float32([[-1.5, -1, 0], [1.5, -1, 0], [1.5, 1, 0], [-1.5, 1, 0], [-2.5, 0, 0], [0, 2, 0]])
+        corners = [(0, 1, 2), (0, 2, 3), (4, 0, 3), (3, 2, 5)][:n]
+        tris = np.zeros(n, abi.tri_dtype)
+        for k, (a, b, c) in enumerate(corners):
+            tris["v0"][k], tris["v1"][k], tris["v2"][k] = fan[a], fan[b], fan[c]
+        tris["materialIndex"] = np.arange(n) % 2
+        return abi.HostScene(tris=tris, materials=mats, params=params, name=kind)
+    spheres = np.zeros(2, abi.sphere_dtype)
+    spheres["center"] = [(-0.8, 0, 0), (0.9, 0.1, -0.5)]
+    spheres["radius"] = [0.7, 0.9]
+    spheres["materialIndex"] = [0, 1]
+    return abi.HostScene(spheres=spheres, materials=mats, params=params, name=kind)
+
+
+@pytest.mark.parametrize("bvh", [abi.BVH_SAH_REFINE, abi.BVH_SAH_REFINE | abi.BVH_WIDE, abi.BVH_LEAF_COLLAPSE, abi.BVH_LEAF_COLLAPSE | abi.BVH_WIDE],
+                         ids=["sah", "sah-wide", "collapse", "collapse-wide"])
+@pytest.mark.parametrize("kind", ["tris2", "tris3", "tris4", "spheres2"])
+def test_scenes_smaller_than_one_leaf(ctx, kind, bvh):
+    w, h = 64, 48
+    scene = _tiny_scene(kind, w, h)
+    ref = None
+    for tracer in (abi.TRACER_MEGAKERNEL, abi.TRACER_WAVEFRONT):
+        img, ids, ps = _gpu_render(ctx, scene, w, h, 2, bvh=bvh, tracer=tracer)
+        if ref is None:
+            ref = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_BRUTE)
+        assert np.array_equal(ids, ref[1]), f"{(ids != ref[1]).sum()} primary-hit ID mismatches"
+        assert np.array_equal(img.view(np.uint32), ref[0].view(np.uint32))
+    assert (ref[1] != abi.ID_MISS).mean() > 0.05
+    nodes, sid, qid, tid = ctx.bvh()
+    _check_tree(nodes, sid, qid, tid, scene)
+    # ray queries, among them rays that start at the world origin (where an all-zero pair 0 used to trap the walk)
+    rays = _query_rays(scene, 600, 5)
+    rays["origin"][:8] = 0
+    got = ctx.rays_query(rays, abi.QUERY_CLOSEST)
+    want = orc.hit_rays(scene, rays, flags=orc.TRAVERSE_BRUTE)
+    assert np.array_equal(got["id"], want["id"])
+    hit = want["id"] != abi.ID_MISS
+    assert np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32))
+
+
+@pytest.mark.parametrize("name,w,h,rng", [("corne", 64, 64, abi.RNG_REF), ("book1", 96, 56, abi.RNG_PCG)], ids=["corne-hash", "book1-pcg"])
+def test_batches_of_64_and_6_iterations(ctx, name, w, h, rng):
+    # 70 iterations = one batch of 64 + one of 6: the batch index packed beside the pixel slot (it << 26 | pix), the
+    # per-iteration seeds and the radiance slots of every batch position, none of which 4-iteration tests reach
+    n = 70
+    scene = abi.builtin_scene(name, w, h)
+    img, ids, ps = _gpu_render(ctx, scene, w, h, n, bvh=abi.BVH_SAH_REFINE | abi.BVH_WIDE, tracer=abi.TRACER_WAVEFRONT, rng_mode=rng)
+    ref_img, ref_ids, _ = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_FAST | (orc.RNG_PCG if rng == abi.RNG_PCG else 0))
+    assert np.array_equal(ids, ref_ids)
+    assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32))
+    assert (img[..., 3] == n).all()
+
+
+def test_one_rank_of_eight_at_4k_16_iterations(ctx):
+    # the headline shape as one of 8 ranks sees it: its bands of the 4K frame, 16 iterations in one batch, against the
+    # oracle's rows
+    w, h, n, rank, world = 3840, 2160, 16, 5, 8
+    scene = abi.builtin_scene("voxel_city", w, h)
+    img, ids, ps = _gpu_render(ctx, scene, w, h, n, bvh=abi.BVH_SAH_REFINE | abi.BVH_WIDE, tracer=abi.TRACER_WAVEFRONT,
+                               band_rank=rank, band_world=world)
+    ref_img, ref_ids, cnt = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_FAST | orc.BANDS(rank, world))
+    rows = abi.band_rows(h, rank, world)
+    assert len(rows) == h // world and cnt.paths == len(rows) * w * n
+    assert np.array_equal(ids[rows], ref_ids[rows])
+    assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32))        # rows of other ranks: zero on both sides
+    assert (img[rows][..., 3] == n).all() and not np.delete(img, rows, axis=0).any()
+
+
+def test_config5_animate_rebuild_and_update(ctx):
+    """BASELINE config 5 in small: crt_tris_animate + crt_bvh_build(LBVH | WIDE) every frame, one sample per frame; the
+    animated triangles are read back and handed to the oracle, which must produce the same bits.  Then crt_tris_update."""
+    w, h = 160, 96
+    scene = abi.builtin_scene("grid:10", w, h)
+    assert len(scene.tris) == 100_000
+    ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+    ctx.upload(scene)
+    seeds = abi.frame_seeds(0, 8)
+    rest = scene.tris
+
+    def check_frame(frame, rest, seed):
+        ctx.animate(float(frame), 0.35)
+        ctx.build(abi.BVH_LBVH | abi.BVH_WIDE)
+        tris = ctx.tris_read()
+        for v in ("v0", "v1", "v2"):
+            x, y, z = (rest[v][:, k].astype(np.float64) for k in range(3))
+            arg = (np.float32(frame) + rest[v][:, 0]) + rest[v][:, 2]             # the kernel's fp32 argument
+            want = y + 0.35 * np.sin(arg.astype(np.float64))
+            assert np.abs(tris[v][:, 1] - want).max() <= 4e-7 * max(1.0, np.abs(want).max())       # sinf <= 2 ulp, one rounding each for * and +
+            assert np.array_equal(tris[v][:, 0], rest[v][:, 0]) and np.array_equal(tris[v][:, 2], rest[v][:, 2])
+        assert np.array_equal(tris["materialIndex"], rest["materialIndex"]) and np.array_equal(tris["u"], rest["u"])
+        p = scene.params_for(1, seed)
+        ctx.render(p, 1, np.float32([seed])); ctx.sync()
+        moved = abi.HostScene(tris=tris, materials=scene.materials, textures=scene.textures, params=scene.params, name="grid-animated")
+        ref_img, ref_ids, _ = orc.render(moved, [p], w, h, flags=orc.TRAVERSE_FAST)
+        assert np.array_equal(ctx.hit_ids(), ref_ids)
+        assert np.array_equal(ctx.image().view(np.uint32), ref_img.view(np.uint32))
+        assert (ref_ids != abi.ID_MISS).mean() > 0.2
+        return tris
+
+    frames = [check_frame(f, rest, seeds[f - 1]) for f in (1, 2, 3)]
+    assert not np.array_equal(frames[0]["v0"], frames[1]["v0"])
+    # crt_tris_update after crt_tris_animate: the new triangles are what the tracer sees now AND the rest pose of the next animate
+    new = rest[:5000].copy()
+    for v in ("v0", "v1", "v2"):
+        new[v][:, 1] += np.float32(1.5)
+    ctx.tris_update(new, first=2000)
+    got = ctx.tris_read(first=2000, count=5000)
+    assert np.array_equal(got.view(np.uint8), new.view(np.uint8))
+    with pytest.raises(abi.CrtError, match="crt_bvh_build has not been called"):
+        ctx.dispatch(scene.params)                                                  # an update invalidates the BVH
+    rest2 = rest.copy()
+    rest2[2000:7000] = new
+    check_frame(4, rest2, seeds[3])
+    with pytest.raises(abi.CrtError, match="range"):
+        ctx.tris_update(new, first=len(rest) - 10)
+
+
+def _nested_scene(n, w, h):
+    """Concentric triangles whose size doubles from one to the next: the sweep SAH peels a few items per level, so the
+    rebuilt tree is far deeper than log2(n) and deeper than the 24-entry LDS stack of the pair tracers."""
+    base = abi.builtin_scene("quads", w, h)
+    tris = np.zeros(n, abi.tri_dtype)
+    s = np.float32(2.0) ** (np.arange(n, dtype=np.float32) - np.float32(n // 2))
+    z = -np.arange(n, dtype=np.float32) * np.float32(1e-3)                   # distinct depths: no ties
+    tris["v0"] = np.stack([-s, -s, z], 1); tris["v1"] = np.stack([s, -s, z], 1); tris["v2"] = np.stack([0 * s, s, z], 1)
+    tris["materialIndex"] = np.arange(n) % 2
+    params = base.params.copy()
+    params["camera"] = abi.camera((0.1, 0.1, 3.0), (0, 0, 0), 60.0, w / h, 0.0, 10.0)
+    return abi.HostScene(tris=tris, materials=base.materials[:2].copy(), params=params, name="nested")
+
+
+def test_deep_sah_tree_is_measured(ctx, monkeypatch):
+    w, h = 64, 48
+    scene = _nested_scene(100, w, h)
+    ref = None
+    for bvh in (abi.BVH_SAH_REFINE, abi.BVH_SAH_REFINE | abi.BVH_WIDE):
+        for tracer in (abi.TRACER_MEGAKERNEL, abi.TRACER_WAVEFRONT):
+            img, ids, ps = _gpu_render(ctx, scene, w, h, 2, bvh=bvh, tracer=tracer)
+            if ref is None:
+                ref = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_BRUTE)
+            assert np.array_equal(ids, ref[1]) and np.array_equal(img.view(np.uint32), ref[0].view(np.uint32))
+    nodes, sid, qid, tid = ctx.bvh()
+    _, depth = _check_tree(nodes, sid, qid, tid, scene)
+    assert depth >= 12, depth                    # log2(100 / 4) would be 5
+    # a tree deeper than the traversal stacks is an error of crt_bvh_build, not a silent stack overflow (the limit is
+    # lowered through its test hook: real scenes do not get near 96 levels)
+    monkeypatch.setenv("CRT_BVH_MAX_PAIR_DEPTH", str(depth - 1))
+    ctx.upload(scene)
+    with pytest.raises(abi.CrtError, match="levels deep"):
+        ctx.build(abi.BVH_SAH_REFINE)
+    with pytest.raises(abi.CrtError, match="crt_bvh_build has not been called"):
+        ctx.dispatch(scene.params)
+    monkeypatch.delenv("CRT_BVH_MAX_PAIR_DEPTH")
+    ctx.build(abi.BVH_SAH_REFINE)
+
+
+def test_dispatch_does_not_wait_for_the_gpu(ctx):
+    # crt_dispatch is asynchronous (abi.h): a burst of dispatches is enqueued without waiting for each one to finish.
+    # Same image as the blocking sequence; last_render_ms is the time of the LAST dispatch once synced.
+    import time
+    w, h = 3840, 2160
+    scene = abi.builtin_scene("corne", w, h)
+    ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+    ctx.upload(scene); ctx.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE)
+    ps, seeds = _params(scene, 6)
+    ctx.dispatch(ps[0]); ctx.sync()
+    one = ctx.stats().last_render_ms
+    t0 = time.perf_counter()
+    for p in ps[1:3]:
+        ctx.dispatch(p)                          # two dispatches fit the two timing slots: neither call waits
+    enqueue_ms = (time.perf_counter() - t0) * 1e3
+    ctx.sync()
+    assert ctx.stats().last_render_ms > 0
+    assert enqueue_ms < 0.6 * one, (enqueue_ms, one)   # a blocking second call would wait for the first: >= one dispatch's device time
+    for p in ps[3:]:
+        ctx.dispatch(p)
+    ctx.sync()
+    a = ctx.image()
+    ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+    ctx.render(ps[0], 1, seeds); ctx.sync()
+    assert np.array_equal(a.view(np.uint32), ctx.image().view(np.uint32))

@@ -71,6 +71,18 @@ def test_traversal_modes_agree(name, w, h, n):
     assert c0.rays == c1.rays == c2.rays and c2.node_visits < c0.prim_tests
 
 
+@pytest.mark.parametrize("name,w,h,n", [("voxel_city", 640, 360, 2), ("cirno", 480, 272, 3)])
+def test_reference_order_vs_canonical_tie_break_on_scenes_that_can_tie(name, w, h, n):
+    # voxel_city: coplanar cube faces sharing edges and corners (the headline stand-in); cirno: a closed mesh whose
+    # triangles share every edge.  A primary ray through a shared edge can hit both neighbours at exactly the same t; the
+    # reference keeps the first one its threaded BVH tests, the build the lowest ID.  SURVEY 8(d): at most 1e-5 of the
+    # primary rays may differ, each by at most 4 ulp of t.
+    sc = abi.builtin_scene(name, w, h, GOLD)
+    rep = orc.tie_break_report(sc, _params(sc, n), w, h)
+    assert rep["primary_id_mismatches"] <= 1e-5 * rep["primary_rays"], rep
+    assert rep["max_ulp_between_mismatching_hits"] <= 4 and rep["hit_vs_miss_mismatches"] == 0, rep
+
+
 def test_default_grid_is_floor_w8_h8():
     sc = abi.builtin_scene("corne", 50, 30)
     a, ids, c = orc.render(sc, _params(sc, 1), 50, 30, flags=orc.TRAVERSE_FAST)
