@@ -95,6 +95,7 @@ def _load():
         "crt_dispatch": (i32, [vp, vp]),
         "crt_render": (i32, [vp, vp, u32, u32, vp]),
         "crt_rays_query": (i32, [vp, vp, u32, u32, vp]),
+        "crt_rays_query_noalloc": (i32, [vp, vp, u32, u32, vp]),
         "crt_sync": (i32, [vp]),
         "crt_image_read": (i32, [vp, vp, C.c_size_t]),
         "crt_hit_ids_read": (i32, [vp, vp, C.c_size_t]),
@@ -333,6 +334,10 @@ class Context:
         out = np.zeros(len(r), dtype=ray_hit_dtype)
         self._check(lib.crt_rays_query(self._h, _ptr(r) if len(r) else None, len(r), mode, _ptr(out) if len(r) else None), "crt_rays_query")
         return out
+
+    def rays_query_noalloc(self, rays_dev_ptr, n_rays, mode, hits_dev_ptr):
+        """crt_rays_query_noalloc: raw device pointers (ints) in, nothing returned; enqueues only."""
+        self._check(lib.crt_rays_query_noalloc(self._h, C.c_void_p(rays_dev_ptr), n_rays, mode, C.c_void_p(hits_dev_ptr)), "crt_rays_query_noalloc")
 
     def sync(self):
         self._check(lib.crt_sync(self._h), "crt_sync")

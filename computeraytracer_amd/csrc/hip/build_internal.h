@@ -97,6 +97,11 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sc, const Frame
 // crt_rays_query: answers n_rays caller rays (host or device memory) with one k_wf_extend launch; synchronous.
 bool launch_ray_query(hipStream_t stream, const DeviceSceneHost &sc, const FrameSetup &fs, WavefrontState &wf, const crt_ray *rays,
                       uint32_t n_rays, uint32_t mode, crt_ray_hit *hits, DeviceStats *stats, std::string &err);
+// crt_rays_query_noalloc: the same query over the library's static device scratch (no allocation, no copy, no wait).
+// noalloc_init(device) looks the scratch's address up once per device, with that device current (crt_create).
+bool noalloc_init(int device, std::string &err);
+bool launch_ray_query_noalloc(hipStream_t stream, int device, const DeviceSceneHost &sc, const FrameSetup &fs, const crt_ray *rays_dev,
+                              uint32_t n_rays, uint32_t mode, crt_ray_hit *hits_dev, DeviceStats *stats, std::string &err);
 void free_wavefront(WavefrontState &wf);
 size_t wavefront_bytes(const WavefrontState &wf);      // device memory the tracer's queues hold right now
 

@@ -197,6 +197,8 @@ int crt_create(int device, crt_context **out) {
     }
     if (hipMalloc(&ctx->stats.ptr, sizeof(DeviceStats)) != hipSuccess || hipMemset(ctx->stats.ptr, 0, sizeof(DeviceStats)) != hipSuccess) { delete ctx; return CRT_ERR_HIP; }
     ctx->stats.bytes = sizeof(DeviceStats);
+    std::string err;
+    if (!noalloc_init(device, err)) { hipError_t e = hipFree(ctx->stats.ptr); (void)e; delete ctx; return CRT_ERR_HIP; }      // this device's copy of the static scratch
     *out = ctx;
     return CRT_OK;
 }
@@ -407,6 +409,34 @@ int crt_rays_query(crt_context *ctx, const crt_ray *rays, uint32_t n_rays, uint3
     fs.small_stack = (ctx->configured && (ctx->cfg.flags & CRT_FLAG_DEBUG_SMALL_STACK)) ? 1u : 0u;
     if (!launch_ray_query(ctx->stream, scene_view(ctx), fs, ctx->wf, rays, n_rays, mode, hits, (DeviceStats *)ctx->stats.ptr, err))
         return fail(ctx, CRT_ERR_HIP, "crt_rays_query: " + err);
+    return CRT_OK;
+}
+
+int crt_rays_query_noalloc(crt_context *ctx, const crt_ray *rays_dev, uint32_t n_rays, uint32_t mode, crt_ray_hit *hits_dev) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!ctx->have_scene) return fail(ctx, CRT_ERR_INVALID, "crt_rays_query_noalloc: crt_scene_upload has not been called");
+    if (!ctx->have_bvh) return fail(ctx, CRT_ERR_INVALID, "crt_rays_query_noalloc: crt_bvh_build has not been called for the current scene");
+    if (mode > CRT_QUERY_ANY) return fail(ctx, CRT_ERR_INVALID, "crt_rays_query_noalloc: unknown mode");
+    if (n_rays > CRT_NOALLOC_MAX_RAYS) return fail(ctx, CRT_ERR_INVALID, "crt_rays_query_noalloc: more than CRT_NOALLOC_MAX_RAYS (131072) rays in one call");
+    if (n_rays == 0) return CRT_OK;
+    if (!rays_dev || !hits_dev) return fail(ctx, CRT_ERR_INVALID, "crt_rays_query_noalloc: null rays/hits");
+    if ((uintptr_t)rays_dev % 16 != 0 || (uintptr_t)hits_dev % 8 != 0) return fail(ctx, CRT_ERR_INVALID, "crt_rays_query_noalloc: rays must be 16-byte and hits 8-byte aligned");
+    // the kernels dereference both pointers: host memory here would be a GPU memory fault, not an error code
+    const void *ptrs[2] = {rays_dev, hits_dev};
+    for (const void *p : ptrs) {
+        hipPointerAttribute_t attr{};
+        if (hipPointerGetAttributes(&attr, p) != hipSuccess || (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)) {
+            hipError_t e = hipGetLastError(); (void)e;     // clear the sticky error of a failed attribute query
+            return fail(ctx, CRT_ERR_INVALID, "crt_rays_query_noalloc: rays and hits must be device memory");
+        }
+        if (attr.type == hipMemoryTypeDevice && attr.device != ctx->device)
+            return fail(ctx, CRT_ERR_INVALID, "crt_rays_query_noalloc: rays and hits must live on the context's GPU");
+    }
+    std::string err;
+    FrameSetup fs{};
+    fs.small_stack = (ctx->configured && (ctx->cfg.flags & CRT_FLAG_DEBUG_SMALL_STACK)) ? 1u : 0u;
+    if (!launch_ray_query_noalloc(ctx->stream, ctx->device, scene_view(ctx), fs, rays_dev, n_rays, mode, hits_dev, (DeviceStats *)ctx->stats.ptr, err))
+        return fail(ctx, CRT_ERR_HIP, "crt_rays_query_noalloc: " + err);
     return CRT_OK;
 }
 

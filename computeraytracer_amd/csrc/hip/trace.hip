@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <mutex>
 
 #include "build_internal.h"
 #include "shade.h"
@@ -670,6 +671,85 @@ bool launch_ray_query(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hits, wf.hit.ptr, (size_t)n_rays * sizeof(crt_ray_hit), hipMemcpyDefault, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    return true;
+}
+
+// ---- crt_rays_query_noalloc: the same launches over a scratch buffer that lives in the code object ------------------
+// For callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  The queue
+// of crt_rays_query (ray origins + directions) and its counter tables sit in a file-scope __device__ array; every GPU
+// the library runs on holds its own copy at its own address, which noalloc_init looks up once per device
+// (hipGetSymbolAddress with that device current).  Host code only ever uses that looked-up pointer: the array's NAME
+// is a host-side stand-in, not a device address.
+constexpr uint32_t kNoAllocMaxRays = CRT_NOALLOC_MAX_RAYS;
+constexpr size_t kNoAllocRayBytes = (size_t)kNoAllocMaxRays * 16;                     // one float4 array
+constexpr size_t kNoAllocCtrBytes = (size_t)kShards * kCtrStride * 4;                 // one counter table (bounce 0 only)
+constexpr size_t kNoAllocBytes = 2 * kNoAllocRayBytes + 2 * kNoAllocCtrBytes;         // 4 MiB + 128 KiB
+static_assert(kNoAllocMaxRays % (64 * 64) == 0, "capacity = whole sub-queues of whole 64-ray tiles");
+static __device__ __align__(256) unsigned char g_noalloc_scratch[kNoAllocBytes];
+
+constexpr int kNoAllocMaxDevices = 64;
+static void *g_noalloc_ptr[kNoAllocMaxDevices];      // per device: address of ITS copy of g_noalloc_scratch (null: not looked up)
+static std::mutex g_noalloc_mutex;
+
+bool noalloc_init(int device, std::string &err) {
+    if (device < 0 || device >= kNoAllocMaxDevices) { err = "device index beyond the no-alloc scratch table"; return false; }
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (g_noalloc_ptr[device]) return true;
+    void *ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_noalloc_scratch)));      // the caller made `device` current
+    if (!ptr) { err = "hipGetSymbolAddress returned a null scratch address"; return false; }
+    g_noalloc_ptr[device] = ptr;
+    return true;
+}
+
+bool launch_ray_query_noalloc(hipStream_t stream, int device, const DeviceSceneHost &sch, const FrameSetup &fs, const crt_ray *rays_dev,
+                              uint32_t n_rays, uint32_t mode, crt_ray_hit *hits_dev, DeviceStats *stats, std::string &err) {
+    if (n_rays == 0) return true;
+    if (n_rays > kNoAllocMaxRays) { err = "at most " + std::to_string(kNoAllocMaxRays) + " rays per call (CRT_NOALLOC_MAX_RAYS); use crt_rays_query for more"; return false; }
+    if (sch.n_pairs + 1 >= kMaxLeafLink) { err = "wavefront tracer supports at most 2^26 primitives"; return false; }
+    unsigned char *base = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+        if (device >= 0 && device < kNoAllocMaxDevices) base = (unsigned char *)g_noalloc_ptr[device];
+    }
+    if (!base) { err = "no-alloc scratch of this device was not initialised (crt_create does it)"; return false; }
+    DeviceScene sc = to_device_scene(sch);
+    WfQueues q{};
+    const uint32_t n_tiles = (n_rays + 63) / 64;
+    q.n_shards = n_tiles >= 64 * 16 ? 64 : 1;
+    q.refill = kRefillLanes; q.leaf_lanes = kLeafLanes;
+    q.tiles_per_shard = (n_tiles + q.n_shards - 1) / q.n_shards;
+    q.shard_cap = q.tiles_per_shard * 64;
+    const size_t cap = (size_t)q.shard_cap * q.n_shards;
+    if (cap > kNoAllocMaxRays) { err = "internal: query capacity beyond the scratch"; return false; }
+    // only queue 0 and bounce 0 are touched by a query; slot == ray index, so the kernel writes its answers straight
+    // into the caller's hits array (slots past n_rays are never produced: a sub-queue's count stops at n_rays)
+    q.ray_o[0] = q.ray_o[1] = (float4 *)base;
+    q.ray_d[0] = q.ray_d[1] = (float4 *)(base + kNoAllocRayBytes);
+    q.thr[0] = q.thr[1] = nullptr;
+    q.hit = (uint2 *)hits_dev;
+    q.counts = (uint32_t *)(base + 2 * kNoAllocRayBytes);
+    q.cursors = (uint32_t *)(base + 2 * kNoAllocRayBytes + kNoAllocCtrBytes);
+    q.lds_depth = fs.small_stack ? 1u : (sc.wide ? (uint32_t)kWideLds : (uint32_t)kLdsStack);
+    uint32_t nb = (uint32_t)((cap + 255) / 256);
+    const uint32_t resident = 256u * CRT_EXTEND_WAVES;
+    nb = nb < resident ? ((nb + 15) / 16) * 16 : resident;
+    const dim3 block(256), pgrid(nb);
+    // the scratch keeps the previous call's contents: k_query_init rewrites every count and cursor word
+    hipLaunchKernelGGL(k_query_init, dim3(1), dim3(256), 0, stream, q, n_rays);
+    hipLaunchKernelGGL(k_query_pack, dim3((n_rays + 255) / 256), block, 0, stream, q, rays_dev, n_rays);
+    const bool any = mode == CRT_QUERY_ANY;
+    if (sc.wide && sch.wide_levels <= q.lds_depth + 1u) {
+        if (any) hipLaunchKernelGGL((k_wf_extend<false, true, false, 2>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
+        else hipLaunchKernelGGL((k_wf_extend<false, true, false, 1>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
+    } else if (sc.wide) {
+        if (any) hipLaunchKernelGGL((k_wf_extend<false, true, true, 2>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
+        else hipLaunchKernelGGL((k_wf_extend<false, true, true, 1>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
+    } else {
+        if (any) hipLaunchKernelGGL((k_wf_extend<false, false, true, 2>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
+        else hipLaunchKernelGGL((k_wf_extend<false, false, true, 1>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
+    }
+    HIP_TRY(hipGetLastError());
     return true;
 }
 

@@ -110,6 +110,16 @@ int crt_render(crt_context *ctx, const crt_scene_params *params, uint32_t first_
  * queues whatever crt_config.tracer says, so do not overlap it with a render on the same context. */
 int crt_rays_query(crt_context *ctx, const crt_ray *rays, uint32_t n_rays, uint32_t mode, crt_ray_hit *hits);
 
+/* crt_rays_query for callers that cannot allocate.  No counterpart in the reference; it exists for code that must not
+ * call hipMalloc: under HIP graph capture, in tight serving loops, in harnesses that forbid allocation.  Same answers
+ * as crt_rays_query (same kernels), but: rays and hits are DEVICE memory (checked), at most CRT_NOALLOC_MAX_RAYS rays
+ * per call (more is an error), the queue lives in a static device array of the library (4.125 MiB per GPU, held until
+ * the process ends) instead of allocated buffers, and the call only enqueues on the context's stream: no hipMalloc,
+ * hipFree, copy through staging or wait; crt_sync (or any stream-ordered use of hits on that stream) waits.
+ * All contexts of one GPU share that GPU's scratch: calls that overlap on one GPU (two contexts, two threads) race;
+ * calls on one context are ordered by its stream. */
+int crt_rays_query_noalloc(crt_context *ctx, const crt_ray *rays_dev, uint32_t n_rays, uint32_t mode, crt_ray_hit *hits_dev);
+
 /* Replaces waitForFences(renderFence) (vk_engine.cpp:1377). */
 int crt_sync(crt_context *ctx);
 

@@ -140,6 +140,10 @@ enum {
     CRT_QUERY_ANY = 1       /* shadow rays: id != CRT_ID_MISS iff SOME primitive is hit in the interval; which one is unspecified */
 };
 
+/* crt_rays_query_noalloc: most rays one call takes (its queue lives in a static device array of
+ * 32 bytes per ray + 128 KiB of counters = 4.125 MiB per GPU). */
+#define CRT_NOALLOC_MAX_RAYS 131072u
+
 /* crt_config.rng_mode */
 enum {
     CRT_RNG_REF = 0,   /* the shader's float-seeded integer hash, compute.comp:116-139 (bit-exact) */
