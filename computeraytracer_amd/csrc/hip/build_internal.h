@@ -32,6 +32,7 @@ struct BuildState {
     DeviceBuffer pairs, tri_pack, sphere_pack, quad_pack, sphere_ids, quad_ids, tri_ids;
     // 8-wide quantised nodes (bvh_wide.hip, CRT_BVH_WIDE): n_wide nodes of kWideStrideF4 float4 each, BFS order
     DeviceBuffer wide, wide_queue[2], wide_levels_dev;
+    DeviceBuffer dp_cost, dp_choice, dp_parent, dp_depth, dp_list, dp_hist;      // collapse table (bvh_wide.hip)
     DeviceBuffer refit_list[2], refit_count[2];      // parked climbers between the stages of the LBVH refit
     uint32_t n_wide = 0, wide_levels = 0;
     uint32_t pair_depth = 0;                         // levels of the SAH-refined pair tree (0: not measured, LBVH <= 95)

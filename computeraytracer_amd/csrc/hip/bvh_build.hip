@@ -574,6 +574,7 @@ void free_build_state(BuildState &st) {
                            &st.scene_bounds, &st.temp, &st.range_lo, &st.range_hi, &st.sah_flag, &st.sah_ipos[0],
                            &st.sah_ipos[1], &st.sah_starts, &st.sah_desc, &st.perm, &st.pairs, &st.tri_pack, &st.sphere_pack, &st.quad_pack, &st.sphere_ids,
                            &st.quad_ids, &st.tri_ids, &st.wide, &st.wide_queue[0], &st.wide_queue[1], &st.wide_levels_dev,
+                           &st.dp_cost, &st.dp_choice, &st.dp_parent, &st.dp_depth, &st.dp_list, &st.dp_hist,
                            &st.refit_list[0], &st.refit_list[1], &st.refit_count[0], &st.refit_count[1]};
     for (DeviceBuffer *b : all) if (b->ptr) { hipError_t e = hipFree(b->ptr); (void)e; b->ptr = nullptr; b->bytes = 0; }
 }

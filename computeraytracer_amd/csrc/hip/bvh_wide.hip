@@ -25,13 +25,22 @@
 // Slots are assigned so that slot ^ octant(ray) is a front-to-back visiting order (Ylitie, Karras, Laine 2017):
 // a child whose centroid lies towards +x/+y/+z of the node centre prefers a slot with bit 0/1/2 set.
 //
-// Collapse: top-down, one thread per wide node, level by level.  A thread starts from the two children of a pair
-// and keeps replacing the inner child of largest surface area by that child's two children until it holds eight
-// children or only leaves.  Wide nodes are numbered in BFS order: index = (nodes of earlier levels) + position in
-// the level's queue, so the inner children of one node are consecutive.
+// Collapse: which inner nodes of the pair BVH become wide nodes is decided by dynamic programming over the whole tree
+// (Ylitie, Karras, Laine 2017, section 4.1), minimising the summed surface area of the wide nodes = the expected
+// number of node visits per ray: c(n, i) = cheapest way to hand the subtree of inner node n to its parent as at most i
+// children.  c(n, 1) = area(n) + min_k [c(left, k) + c(right, 8 - k)] (n becomes a wide node), c(n, i) = min(c(n, i - 1),
+// min_k [c(left, k) + c(right, i - k)]) (n is dissolved into its parent); a leaf costs nothing extra and takes one slot.
+// Bottom-up: the pairs are bucketed by depth and one launch handles one depth, deepest first.  The greedy rule this
+// replaces (keep expanding the child of largest area) left 31 % of the nodes of the 224,998-triangle scene with two
+// children; see DESIGN.md for the measured difference.  Then top-down, one thread per wide node, level by level: a
+// thread starts from the two children of a pair with the budgets the table prescribes and keeps dissolving inner
+// children whose budget is larger than one.  Wide nodes are numbered in BFS order: index = (nodes of earlier levels) +
+// position in the level's queue, so the inner children of one node are consecutive.  CRT_WIDE_GREEDY=1 (environment)
+// selects the old rule for A/B runs.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 
 #include "build_internal.h"
@@ -42,7 +51,7 @@ namespace crt {
 constexpr uint32_t kWideLeafTag = 0x80000000u;
 constexpr uint32_t kWideEmptyLink = kWideLeafTag | (3u << 29);
 
-struct WideChild { float lo[3], hi[3]; uint32_t link, count; };
+struct WideChild { float lo[3], hi[3]; uint32_t link, count, budget; };
 
 __device__ __forceinline__ bool pad_leaf(uint32_t count) { return count != 0u && (count & 0x0FFFFFFFu) == 0u; }
 
@@ -50,6 +59,84 @@ __device__ __forceinline__ void read_half(const float4 *half, WideChild &c) {
     float4 a = half[0], b = half[1];
     c.lo[0] = a.x; c.lo[1] = a.y; c.lo[2] = a.z; c.link = __float_as_uint(a.w);
     c.hi[0] = b.x; c.hi[1] = b.y; c.hi[2] = b.z; c.count = __float_as_uint(b.w);
+    c.budget = 1u;
+}
+
+// ---- the table ----------------------------------------------------------------------------------------------------
+// choice word of inner node n (64 bits): bits 3 (j - 2) .. +2 = k of the best split of j slots between its children
+// (j = 2 .. 8: left gets k, right j - k); bits 21 + 3 (i - 1) .. +2 = eff(i), i = 1 .. 7: the number of slots n actually
+// uses when it is offered i (1 = n stays a wide node of its own).
+constexpr uint32_t kDpLevels = 128;      // pair trees are at most 96 deep (kMaxPairDepth), LBVH ones at most 95
+struct DpLevels { uint32_t start[kDpLevels + 1]; };
+
+__global__ void k_dp_parents(uint32_t n_halves, const float4 *pairs, uint32_t *parent) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_halves) return;
+    const uint32_t count = __float_as_uint(pairs[2 * (size_t)h + 1].w), link = __float_as_uint(pairs[2 * (size_t)h].w);
+    if (count == 0u && link != 0u && link < n_halves / 2u) parent[link] = h >> 1;      // link 0: a hole (the root is nobody's child)
+}
+
+// depth[p] = number of pairs on the way from p up to the root (root = 1, unreachable holes = 0), hist[d] = pairs of depth d
+__global__ void k_dp_depth(uint32_t n_pairs, const uint32_t *parent, uint32_t *depth, uint32_t *hist) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    uint32_t d = 1, q = parent[p];
+    while (q != 0xFFFFFFFFu && q != 0u && d < kDpLevels) { d++; q = parent[q]; }
+    if (p != 0u && q == 0xFFFFFFFFu) d = 0;              // walked off the top without meeting the root: not part of the tree
+    else if (p != 0u) d++;                                // the root itself
+    if (d >= kDpLevels) d = kDpLevels - 1;               // cannot happen (depth checked at build); keeps the table in bounds
+    depth[p] = d;
+    if (d) atomicAdd(&hist[d], 1u);
+}
+
+__global__ void k_dp_scatter(uint32_t n_pairs, const uint32_t *depth, DpLevels lv, uint32_t *cursor, uint32_t *list) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t d = depth[p];
+    if (d) list[lv.start[d] + atomicAdd(&cursor[d], 1u)] = p;
+}
+
+__global__ void k_dp_level(const float4 *pairs, const uint32_t *list, uint32_t first, uint32_t count, float *cost, unsigned long long *choice) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t n = list[first + i];
+    WideChild a, b;
+    read_half(pairs + 4 * (size_t)n, a);
+    read_half(pairs + 4 * (size_t)n + 2, b);
+    float cl[8], cr[8];                                   // index 1 .. 7
+#pragma unroll
+    for (int k = 1; k < 8; k++) { cl[k] = a.count == 0u ? cost[7 * (size_t)a.link + (k - 1)] : 0.0f; cr[k] = b.count == 0u ? cost[7 * (size_t)b.link + (k - 1)] : 0.0f; }
+    float lo[3], hi[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) { lo[ax] = fminf(a.lo[ax], b.lo[ax]); hi[ax] = fmaxf(a.hi[ax], b.hi[ax]); }
+    const float area = half_area3(lo, hi);
+    float dist[9]; uint32_t split[9];
+#pragma unroll
+    for (int j = 2; j <= 8; j++) {
+        float best = 3.402823466e38f; uint32_t bk = 1;
+#pragma unroll
+        for (int k = 1; k < j; k++) {
+            if (k > 7 || j - k > 7) continue;
+            const float v = cl[k] + cr[j - k];
+            if (v < best) { best = v; bk = (uint32_t)k; }
+        }
+        dist[j] = best; split[j] = bk;
+    }
+    float c[8]; uint32_t eff[8];
+    c[1] = area + dist[8]; eff[1] = 1u;
+    if (!(c[1] < 3.402823466e38f)) c[1] = 3.402823466e38f;      // NaN / overflow areas: still a valid (finite) table
+#pragma unroll
+    for (int k = 2; k < 8; k++) {
+        const bool take = dist[k] < c[k - 1];
+        c[k] = take ? dist[k] : c[k - 1];
+        eff[k] = take ? (uint32_t)k : eff[k - 1];
+    }
+    unsigned long long w = 0ull;
+#pragma unroll
+    for (int j = 2; j <= 8; j++) w |= (unsigned long long)split[j] << (3 * (j - 2));
+#pragma unroll
+    for (int k = 1; k < 8; k++) { w |= (unsigned long long)eff[k] << (21 + 3 * (k - 1)); cost[7 * (size_t)n + (k - 1)] = c[k]; }
+    choice[n] = w;
 }
 
 // The eight children of a node under construction live in registers: every index into c[] below comes from a fully
@@ -58,7 +145,7 @@ __device__ __forceinline__ void read_half(const float4 *half, WideChild &c) {
 __device__ __forceinline__ void take_if(WideChild &dst, const WideChild &v, bool p) {      // field-wise selects, never a conditional store
 #pragma unroll
     for (int a = 0; a < 3; a++) { dst.lo[a] = p ? v.lo[a] : dst.lo[a]; dst.hi[a] = p ? v.hi[a] : dst.hi[a]; }
-    dst.link = p ? v.link : dst.link; dst.count = p ? v.count : dst.count;
+    dst.link = p ? v.link : dst.link; dst.count = p ? v.count : dst.count; dst.budget = p ? v.budget : dst.budget;
 }
 struct WideSet {
     WideChild c[8];
@@ -75,7 +162,7 @@ struct WideSet {
 };
 
 // level_count[l] = wide nodes of level l (queue length); level l reads queue l & 1 and appends to the other one.
-__global__ __launch_bounds__(128) void k_wide_level(const float4 *pairs, uint32_t level, uint32_t *level_count,
+__global__ __launch_bounds__(128) void k_wide_level(const float4 *pairs, const unsigned long long *choice, uint32_t level, uint32_t *level_count,
                                                     const uint2 *q_in, uint2 *q_out, float4 *wide, uint32_t stride_f4) {
     const uint32_t n_in = level_count[level];
     uint32_t next_base = 0;                         // nodes of levels 0..level = index of the first node of level + 1
@@ -85,27 +172,43 @@ __global__ __launch_bounds__(128) void k_wide_level(const float4 *pairs, uint32_
         const uint32_t src = w.x, dst = w.y;
         WideSet S;
 #pragma unroll
-        for (int k = 0; k < 8; k++) { for (int a = 0; a < 3; a++) { S.c[k].lo[a] = 0.0f; S.c[k].hi[a] = 0.0f; } S.c[k].link = 0u; S.c[k].count = 0u; }
+        for (int k = 0; k < 8; k++) { for (int a = 0; a < 3; a++) { S.c[k].lo[a] = 0.0f; S.c[k].hi[a] = 0.0f; } S.c[k].link = 0u; S.c[k].count = 0u; S.c[k].budget = 1u; }
         int n = 0;
         {
             WideChild a, b;
             read_half(pairs + 4 * (size_t)src, a);
             read_half(pairs + 4 * (size_t)src + 2, b);
+            if (choice) { const uint32_t k8 = (uint32_t)(choice[src] >> 18) & 7u; a.budget = k8; b.budget = 8u - k8; }      // best split of 8 slots
             if (!pad_leaf(a.count)) { S.set(n, a); n++; }
             if (!pad_leaf(b.count)) { S.set(n, b); n++; }
         }
         while (n < 8) {
-            int best = -1; float best_area = -1.0f; uint32_t best_link = 0;
+            int best = -1; float best_area = -1.0f; uint32_t best_link = 0, best_budget = 1;
+            unsigned long long best_word = 0ull;
+            if (choice) {
+                // an inner child that the table dissolves when offered its budget (eff > 1); any order gives the same set
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (k >= n || S.c[k].count != 0u) continue;
-                const float a = half_area3(S.c[k].lo, S.c[k].hi);
-                if (a > best_area) { best_area = a; best = k; best_link = S.c[k].link; }
+                for (int k = 0; k < 8; k++) {
+                    if (k >= n || S.c[k].count != 0u || S.c[k].budget < 2u || best >= 0) continue;
+                    const unsigned long long w = choice[S.c[k].link];
+                    const uint32_t bud = S.c[k].budget > 7u ? 7u : S.c[k].budget;
+                    const uint32_t eff = (uint32_t)(w >> (21 + 3 * (bud - 1u))) & 7u;
+                    if (eff > 1u) { best = k; best_link = S.c[k].link; best_budget = eff; best_word = w; }
+                    else S.c[k].budget = 1u;      // stays a wide node of its own: do not look at it again
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (k >= n || S.c[k].count != 0u) continue;
+                    const float a = half_area3(S.c[k].lo, S.c[k].hi);
+                    if (a > best_area) { best_area = a; best = k; best_link = S.c[k].link; }
+                }
             }
             if (best < 0) break;
             WideChild a, b;
             read_half(pairs + 4 * (size_t)best_link, a);
             read_half(pairs + 4 * (size_t)best_link + 2, b);
+            if (choice) { const uint32_t kk = (uint32_t)(best_word >> (3 * (best_budget - 2u))) & 7u; a.budget = kk; b.budget = best_budget - kk; }
             const bool pa = pad_leaf(a.count), pb = pad_leaf(b.count);
             if (pa && pb) { S.set(best, S.get(n - 1)); n--; continue; }
             if (pa) { S.set(best, b); continue; }
@@ -233,6 +336,31 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
     if (!ensure_w(st.wide_queue[0], (size_t)st.n_pairs * 8, err) || !ensure_w(st.wide_queue[1], (size_t)st.n_pairs * 8, err)) return false;
     if (!ensure_w(st.wide_levels_dev, (kWideMaxLevels + 2) * 4, err)) return false;
     uint32_t *lc = (uint32_t *)st.wide_levels_dev.ptr;
+    // ---- the table: parents -> depths -> buckets -> one launch per depth, deepest first --------------------------------
+    static const bool greedy = [] { const char *e = getenv("CRT_WIDE_GREEDY"); return e && atoi(e) != 0; }();
+    const unsigned long long *choice = nullptr;
+    if (!greedy && st.n_pairs > 1) {
+        const uint32_t np = st.n_pairs, halves = 2 * np;
+        if (!ensure_w(st.dp_cost, (size_t)np * 7 * 4, err) || !ensure_w(st.dp_choice, (size_t)np * 8, err) || !ensure_w(st.dp_parent, (size_t)np * 4, err) ||
+            !ensure_w(st.dp_depth, (size_t)np * 4, err) || !ensure_w(st.dp_list, (size_t)np * 4, err) || !ensure_w(st.dp_hist, 2 * kDpLevels * 4, err)) return false;
+        uint32_t *hist = (uint32_t *)st.dp_hist.ptr, *cursor = hist + kDpLevels;
+        HIP_TRY(hipMemsetAsync(st.dp_parent.ptr, 0xFF, (size_t)np * 4, stream));
+        HIP_TRY(hipMemsetAsync(hist, 0, 2 * kDpLevels * 4, stream));
+        hipLaunchKernelGGL(k_dp_parents, dim3((halves + 255) / 256), dim3(256), 0, stream, halves, (const float4 *)st.pairs.ptr, (uint32_t *)st.dp_parent.ptr);
+        hipLaunchKernelGGL(k_dp_depth, dim3((np + 255) / 256), dim3(256), 0, stream, np, (const uint32_t *)st.dp_parent.ptr, (uint32_t *)st.dp_depth.ptr, hist);
+        uint32_t host_hist[kDpLevels];
+        HIP_TRY(hipMemcpyAsync(host_hist, hist, kDpLevels * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        DpLevels lv; lv.start[0] = 0; lv.start[1] = 0;
+        uint32_t deepest = 0;
+        for (uint32_t d = 1; d < kDpLevels; d++) { lv.start[d + 1] = lv.start[d] + host_hist[d]; if (host_hist[d]) deepest = d; }
+        hipLaunchKernelGGL(k_dp_scatter, dim3((np + 255) / 256), dim3(256), 0, stream, np, (const uint32_t *)st.dp_depth.ptr, lv, cursor, (uint32_t *)st.dp_list.ptr);
+        for (uint32_t d = deepest; d >= 1; d--)
+            if (host_hist[d]) hipLaunchKernelGGL(k_dp_level, dim3((host_hist[d] + 127) / 128), dim3(128), 0, stream, (const float4 *)st.pairs.ptr, (const uint32_t *)st.dp_list.ptr,
+                               lv.start[d], host_hist[d], (float *)st.dp_cost.ptr, (unsigned long long *)st.dp_choice.ptr);
+        HIP_TRY(hipGetLastError());
+        choice = (const unsigned long long *)st.dp_choice.ptr;
+    }
     hipLaunchKernelGGL(k_wide_init, dim3(1), dim3(128), 0, stream, lc, kWideMaxLevels + 1, (uint2 *)st.wide_queue[0].ptr);
     const uint32_t grid = std::min<uint32_t>(2048u, (st.n_pairs + 127u) / 128u);
     uint32_t host_lc[kWideMaxLevels + 2];
@@ -240,7 +368,7 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
     for (;;) {
         const uint32_t chunk_end = std::min<uint32_t>(level + 8u, kWideMaxLevels);
         for (; level < chunk_end; level++)
-            hipLaunchKernelGGL(k_wide_level, dim3(grid), dim3(128), 0, stream, (const float4 *)st.pairs.ptr, level, lc,
+            hipLaunchKernelGGL(k_wide_level, dim3(grid), dim3(128), 0, stream, (const float4 *)st.pairs.ptr, choice, level, lc,
                                (const uint2 *)st.wide_queue[level & 1].ptr, (uint2 *)st.wide_queue[(level & 1) ^ 1].ptr,
                                (float4 *)st.wide.ptr, kWideStrideF4);
         HIP_TRY(hipGetLastError());
