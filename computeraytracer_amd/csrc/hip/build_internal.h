@@ -36,16 +36,20 @@ struct BuildState {
     DeviceBuffer refit_list[2], refit_count[2];      // parked climbers between the stages of the LBVH refit
     uint32_t n_wide = 0, wide_levels = 0;
     uint32_t pair_depth = 0;                         // levels of the SAH-refined pair tree (0: not measured, LBVH <= 95)
+    bool levels_measured = false;                    // level_hist / dp_depth describe the current pairs (bvh_sah.hip: measure_pair_depths)
+    uint32_t level_hist[128] = {};                   // pairs per depth (root = 1)
 };
 
 constexpr uint32_t kWideStrideF4 = 8;     // 128-byte node stride: the 64 bytes a step loads never straddle a line
 constexpr uint32_t kWideMaxLevels = 64;
+constexpr uint32_t kPairLevels = 128;      // bins of the depth histogram (> kMaxPairDepth)
 constexpr uint32_t kMaxPairDepth = 96;    // pair trees deeper than this are refused: a walk pushes at most depth - 1 entries and the
                                           // stacks hold at least 1 (LDS, debug minimum) + 96 (scratch), intersect.h
 
 bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildState &st, std::string &err);
 bool build_sah(hipStream_t stream, const BuildInput &in, BuildState &st, const uint32_t *vals, std::string &err);
 bool patch_sah_links(hipStream_t stream, BuildState &st, std::string &err);
+bool measure_pair_depths(hipStream_t stream, BuildState &st, std::string &err);
 bool build_wide(hipStream_t stream, BuildState &st, std::string &err);
 bool animate_tris(hipStream_t stream, uint32_t n, const crt_tri *rest, crt_tri *out, float frame, float amplitude, std::string &err);
 void free_build_state(BuildState &st);

@@ -143,7 +143,8 @@ __global__ void k_pack(BuildInput in, uint32_t n, const uint32_t *vals, const ui
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     uint32_t g = vals[s];
-    uint32_t rs = rank_sphere[s], rq = rank_quad[s];
+    // rank arrays are null when the scene holds one kind of primitive: every sorted position is that kind's slot
+    uint32_t rs = rank_sphere ? rank_sphere[s] : (in.n_spheres == n ? s : 0u), rq = rank_quad ? rank_quad[s] : (in.n_quads == n ? s : 0u);
     if (g < in.n_spheres) {
         const crt_sphere &sp = in.spheres[g];
         sphere_pack[rs] = make_float4(sp.center[0], sp.center[1], sp.center[2], sp.radius);
@@ -446,7 +447,7 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     const uint32_t n = in.n_spheres + in.n_quads + in.n_tris;
     st.n_prims = n;
     st.n_pairs = n == 0 ? 0 : (n == 1 ? 1 : n - 1);
-    st.n_wide = 0; st.wide_levels = 0;
+    st.n_wide = 0; st.wide_levels = 0; st.levels_measured = false; st.pair_depth = 0;
     const bool wide = (flags & CRT_BVH_WIDE) != 0;
     if (n == 0) return true;
     const uint32_t blocks = (n + 255) / 256;
@@ -514,16 +515,21 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     }
     st.sorted_vals = order;
 
-    hipLaunchKernelGGL(k_kind_flags, dim3(blocks), dim3(256), 0, stream, n, order, in.n_spheres, in.n_quads,
-                       (uint32_t *)st.flag_a.ptr, (uint32_t *)st.flag_b.ptr);
-    tb = st.temp.bytes;
-    HIP_TRY(rocprim::exclusive_scan(st.temp.ptr, tb, (uint32_t *)st.flag_a.ptr, (uint32_t *)st.rank_a.ptr, 0u, n,
-                                    rocprim::plus<uint32_t>(), stream));
-    tb = st.temp.bytes;
-    HIP_TRY(rocprim::exclusive_scan(st.temp.ptr, tb, (uint32_t *)st.flag_b.ptr, (uint32_t *)st.rank_b.ptr, 0u, n,
-                                    rocprim::plus<uint32_t>(), stream));
-    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, stream, in, n, order, (const uint32_t *)st.rank_a.ptr,
-                       (const uint32_t *)st.rank_b.ptr, (float4 *)st.tri_pack.ptr, (float4 *)st.sphere_pack.ptr,
+    // slot of a sorted position inside its kind's array = number of earlier positions of that kind: two scans, skipped
+    // (with the flag kernel) when the scene holds a single kind, as triangle meshes do
+    const bool mixed = !(in.n_spheres == n || in.n_quads == n || in.n_tris == n);
+    if (mixed) {
+        hipLaunchKernelGGL(k_kind_flags, dim3(blocks), dim3(256), 0, stream, n, order, in.n_spheres, in.n_quads,
+                           (uint32_t *)st.flag_a.ptr, (uint32_t *)st.flag_b.ptr);
+        tb = st.temp.bytes;
+        HIP_TRY(rocprim::exclusive_scan(st.temp.ptr, tb, (uint32_t *)st.flag_a.ptr, (uint32_t *)st.rank_a.ptr, 0u, n,
+                                        rocprim::plus<uint32_t>(), stream));
+        tb = st.temp.bytes;
+        HIP_TRY(rocprim::exclusive_scan(st.temp.ptr, tb, (uint32_t *)st.flag_b.ptr, (uint32_t *)st.rank_b.ptr, 0u, n,
+                                        rocprim::plus<uint32_t>(), stream));
+    }
+    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, stream, in, n, order, mixed ? (const uint32_t *)st.rank_a.ptr : nullptr,
+                       mixed ? (const uint32_t *)st.rank_b.ptr : nullptr, (float4 *)st.tri_pack.ptr, (float4 *)st.sphere_pack.ptr,
                        (float4 *)st.quad_pack.ptr, (uint32_t *)st.sphere_ids.ptr, (uint32_t *)st.quad_ids.ptr,
                        (uint32_t *)st.tri_ids.ptr, (uint32_t *)st.leaf_link.ptr, (uint32_t *)st.leaf_count.ptr);
     HIP_TRY(hipGetLastError());

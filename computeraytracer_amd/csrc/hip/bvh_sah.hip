@@ -474,43 +474,63 @@ bool build_sah(hipStream_t stream, const BuildInput &in, BuildState &st, const u
 // Depth of the rebuilt pair tree.  The Karras LBVH is at most 95 levels deep (63 Morton bits + 32 index bits), which is
 // what the traversal stacks are sized for (intersect.h: kLdsStack + kSpillStack); the SAH rebuild has no such bound (a
 // sweep can peel one item per level, in every tier), so it is measured and the build refuses a tree the pair tracers
-// could not walk.  parent[] of a pair = the pair that links to it (a real inner child never links to pair 0: the root
-// is nobody's child, so link 0 marks the holes left by multi-primitive leaves).
+// could not walk.  The same pass buckets the pairs by depth for the wide collapse's bottom-up table (bvh_wide.hip):
+// parent[] of a pair = the pair that links to it (a real inner child never links to pair 0: the root is nobody's
+// child, so link 0 marks the holes left by multi-primitive leaves); depth = pairs on the way up to the root; one
+// histogram over depths, aggregated per workgroup in LDS (a handful of bins: per-thread global atomics on them took
+// 0.5 ms for 225 k pairs).
 __global__ void k_pair_parents(uint32_t n_halves, const float4 *pairs, uint32_t *parent) {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= n_halves) return;
     const uint32_t count = __float_as_uint(pairs[2 * (size_t)h + 1].w), link = __float_as_uint(pairs[2 * (size_t)h].w);
     if (count == 0u && link != 0u && link < n_halves / 2u) parent[link] = h >> 1;
 }
-__global__ void k_pair_depth(uint32_t n_pairs, const uint32_t *parent, uint32_t *max_depth) {
+__global__ __launch_bounds__(256) void k_pair_depth(uint32_t n_pairs, const uint32_t *parent, uint32_t *depth, uint32_t *hist) {
+    __shared__ uint32_t s_hist[kPairLevels];
+    for (uint32_t i = threadIdx.x; i < kPairLevels; i += blockDim.x) s_hist[i] = 0u;
+    __syncthreads();
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t d = 0;
     if (p < n_pairs) {
-        d = 1;
-        for (uint32_t q = parent[p]; q != 0xFFFFFFFFu && d <= n_pairs; q = parent[q]) d++;      // d <= n_pairs: a corrupt table cannot hang the kernel
+        uint32_t d = 1, q = parent[p];                      // root: 1
+        if (p != 0u) {
+            while (q != 0xFFFFFFFFu && q != 0u && d < kPairLevels) { d++; q = parent[q]; }
+            d = q == 0u ? d + 1u : 0u;                      // met the root: count it; walked off the top: a hole, not part of the tree
+        }
+        if (d >= kPairLevels) d = kPairLevels - 1u;         // deeper than any tree the build accepts; keeps the table in bounds (and fails the depth check)
+        depth[p] = d;
+        if (d) atomicAdd(&s_hist[d], 1u);
     }
-    for (int off = 32; off > 0; off >>= 1) d = max(d, (uint32_t)__shfl_xor((int)d, off));
-    if ((threadIdx.x & 63u) == 0u && d) atomicMax(max_depth, d);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kPairLevels; i += blockDim.x) if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
+}
+
+// Launches the parent / depth / histogram pass over st.pairs and reads the histogram back (one synchronisation):
+// st.level_hist[d] = pairs of depth d, st.pair_depth = the deepest level.
+bool measure_pair_depths(hipStream_t stream, BuildState &st, std::string &err) {
+    const uint32_t np = st.n_pairs, halves = 2 * np;
+    if (!ensure_buf(st.dp_parent, (size_t)np * 4, err) || !ensure_buf(st.dp_depth, (size_t)np * 4, err) || !ensure_buf(st.dp_hist, 2 * kPairLevels * 4, err)) return false;
+    HIP_TRY(hipMemsetAsync(st.dp_parent.ptr, 0xFF, (size_t)np * 4, stream));
+    HIP_TRY(hipMemsetAsync(st.dp_hist.ptr, 0, 2 * kPairLevels * 4, stream));
+    hipLaunchKernelGGL(k_pair_parents, dim3((halves + 255) / 256), dim3(256), 0, stream, halves, (const float4 *)st.pairs.ptr, (uint32_t *)st.dp_parent.ptr);
+    hipLaunchKernelGGL(k_pair_depth, dim3((np + 255) / 256), dim3(256), 0, stream, np, (const uint32_t *)st.dp_parent.ptr, (uint32_t *)st.dp_depth.ptr, (uint32_t *)st.dp_hist.ptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(st.level_hist, st.dp_hist.ptr, kPairLevels * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    st.pair_depth = 0;
+    for (uint32_t d = 1; d < kPairLevels; d++) if (st.level_hist[d]) st.pair_depth = d;
+    st.levels_measured = true;
+    return true;
 }
 
 bool patch_sah_links(hipStream_t stream, BuildState &st, std::string &err) {
     const uint32_t halves = 2 * st.n_pairs;
     hipLaunchKernelGGL(k_sah_patch_links, dim3((halves + 255) / 256), dim3(256), 0, stream, halves, (float4 *)st.pairs.ptr, (const uint32_t *)st.leaf_link.ptr);
-    // st.parent (the LBVH's parent table, 2n words) is free again after build_sah; word 8 of scene_bounds holds the result
-    uint32_t *parent = (uint32_t *)st.parent.ptr, *depth_dev = (uint32_t *)st.scene_bounds.ptr + 8;
-    HIP_TRY(hipMemsetAsync(parent, 0xFF, (size_t)st.n_pairs * 4, stream));
-    HIP_TRY(hipMemsetAsync(depth_dev, 0, 4, stream));
-    hipLaunchKernelGGL(k_pair_parents, dim3((halves + 255) / 256), dim3(256), 0, stream, halves, (const float4 *)st.pairs.ptr, parent);
-    hipLaunchKernelGGL(k_pair_depth, dim3((st.n_pairs + 255) / 256), dim3(256), 0, stream, st.n_pairs, (const uint32_t *)parent, depth_dev);
     HIP_TRY(hipGetLastError());
-    uint32_t depth = 0;
-    HIP_TRY(hipMemcpyAsync(&depth, depth_dev, 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    st.pair_depth = depth;
+    if (!measure_pair_depths(stream, st, err)) return false;
     uint32_t limit = kMaxPairDepth;
     if (const char *e = getenv("CRT_BVH_MAX_PAIR_DEPTH")) { const int v = atoi(e); if (v >= 1 && (uint32_t)v < limit) limit = (uint32_t)v; }   // test hook: can only lower it
-    if (depth > limit) {
-        err = "SAH-refined tree is " + std::to_string(depth) + " levels deep; the pair traversal stacks hold " + std::to_string(limit);
+    if (st.pair_depth > limit) {
+        err = "SAH-refined tree is " + std::to_string(st.pair_depth) + " levels deep; the pair traversal stacks hold " + std::to_string(limit);
         return false;
     }
     return true;

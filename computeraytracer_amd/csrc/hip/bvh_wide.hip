@@ -66,34 +66,23 @@ __device__ __forceinline__ void read_half(const float4 *half, WideChild &c) {
 // choice word of inner node n (64 bits): bits 3 (j - 2) .. +2 = k of the best split of j slots between its children
 // (j = 2 .. 8: left gets k, right j - k); bits 21 + 3 (i - 1) .. +2 = eff(i), i = 1 .. 7: the number of slots n actually
 // uses when it is offered i (1 = n stays a wide node of its own).
-constexpr uint32_t kDpLevels = 128;      // pair trees are at most 96 deep (kMaxPairDepth), LBVH ones at most 95
+constexpr uint32_t kDpLevels = kPairLevels;      // pair trees are at most 96 deep (kMaxPairDepth), LBVH ones at most 95
 struct DpLevels { uint32_t start[kDpLevels + 1]; };
 
-__global__ void k_dp_parents(uint32_t n_halves, const float4 *pairs, uint32_t *parent) {
-    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= n_halves) return;
-    const uint32_t count = __float_as_uint(pairs[2 * (size_t)h + 1].w), link = __float_as_uint(pairs[2 * (size_t)h].w);
-    if (count == 0u && link != 0u && link < n_halves / 2u) parent[link] = h >> 1;      // link 0: a hole (the root is nobody's child)
-}
-
-// depth[p] = number of pairs on the way from p up to the root (root = 1, unreachable holes = 0), hist[d] = pairs of depth d
-__global__ void k_dp_depth(uint32_t n_pairs, const uint32_t *parent, uint32_t *depth, uint32_t *hist) {
+// Buckets the pairs by depth: list[start[d] ..] = the pairs of depth d (any order).  Ranks inside a workgroup come from LDS
+// atomics, one global atomic per workgroup and depth reserves the workgroup's run.
+__global__ __launch_bounds__(256) void k_dp_scatter(uint32_t n_pairs, const uint32_t *depth, DpLevels lv, uint32_t *cursor, uint32_t *list) {
+    __shared__ uint32_t s_cnt[kDpLevels], s_base[kDpLevels];
+    for (uint32_t i = threadIdx.x; i < kDpLevels; i += blockDim.x) s_cnt[i] = 0u;
+    __syncthreads();
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
-    uint32_t d = 1, q = parent[p];
-    while (q != 0xFFFFFFFFu && q != 0u && d < kDpLevels) { d++; q = parent[q]; }
-    if (p != 0u && q == 0xFFFFFFFFu) d = 0;              // walked off the top without meeting the root: not part of the tree
-    else if (p != 0u) d++;                                // the root itself
-    if (d >= kDpLevels) d = kDpLevels - 1;               // cannot happen (depth checked at build); keeps the table in bounds
-    depth[p] = d;
-    if (d) atomicAdd(&hist[d], 1u);
-}
-
-__global__ void k_dp_scatter(uint32_t n_pairs, const uint32_t *depth, DpLevels lv, uint32_t *cursor, uint32_t *list) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
-    const uint32_t d = depth[p];
-    if (d) list[lv.start[d] + atomicAdd(&cursor[d], 1u)] = p;
+    const uint32_t d = p < n_pairs ? depth[p] : 0u;
+    uint32_t r = 0;
+    if (d) r = atomicAdd(&s_cnt[d], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kDpLevels; i += blockDim.x) if (s_cnt[i]) s_base[i] = atomicAdd(&cursor[i], s_cnt[i]);
+    __syncthreads();
+    if (d) list[lv.start[d] + s_base[d] + r] = p;
 }
 
 __global__ void k_dp_level(const float4 *pairs, const uint32_t *list, uint32_t first, uint32_t count, float *cost, unsigned long long *choice) {
@@ -161,15 +150,11 @@ struct WideSet {
     }
 };
 
-// level_count[l] = wide nodes of level l (queue length); level l reads queue l & 1 and appends to the other one.
-__global__ __launch_bounds__(128) void k_wide_level(const float4 *pairs, const unsigned long long *choice, uint32_t level, uint32_t *level_count,
-                                                    const uint2 *q_in, uint2 *q_out, float4 *wide, uint32_t stride_f4) {
-    const uint32_t n_in = level_count[level];
-    uint32_t next_base = 0;                         // nodes of levels 0..level = index of the first node of level + 1
-    for (uint32_t l = 0; l <= level; l++) next_base += level_count[l];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
-        const uint2 w = q_in[i];
-        const uint32_t src = w.x, dst = w.y;
+// One wide node: collapses the subtree of pair `src` into node `dst` of level `level`; its inner children are appended
+// to q_out (the queue of level + 1) and numbered next_base + position (next_base = nodes of levels 0 .. level).
+__device__ __forceinline__ void wide_emit(const float4 *pairs, const unsigned long long *choice, uint32_t level, uint32_t *level_count,
+                                          uint32_t next_base, uint32_t src, uint32_t dst, uint2 *q_out, float4 *wide, uint32_t stride_f4) {
+    {
         WideSet S;
 #pragma unroll
         for (int k = 0; k < 8; k++) { for (int a = 0; a < 3; a++) { S.c[k].lo[a] = 0.0f; S.c[k].hi[a] = 0.0f; } S.c[k].link = 0u; S.c[k].count = 0u; S.c[k].budget = 1u; }
@@ -311,6 +296,45 @@ __global__ __launch_bounds__(128) void k_wide_level(const float4 *pairs, const u
     }
 }
 
+// level_count[l] = wide nodes of level l (queue length); level l reads queue l & 1 and appends to the other one.
+// Levels below *first_level were already emitted by k_wide_top.
+__global__ __launch_bounds__(128) void k_wide_level(const float4 *pairs, const unsigned long long *choice, uint32_t level, uint32_t *level_count,
+                                                    const uint32_t *first_level, const uint2 *q_in, uint2 *q_out, float4 *wide, uint32_t stride_f4) {
+    if (level < *first_level) return;
+    const uint32_t n_in = level_count[level];
+    uint32_t next_base = 0;                         // nodes of levels 0..level = index of the first node of level + 1
+    for (uint32_t l = 0; l <= level; l++) next_base += level_count[l];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
+        const uint2 w = q_in[i];
+        wide_emit(pairs, choice, level, level_count, next_base, w.x, w.y, q_out, wide, stride_f4);
+    }
+}
+
+// The first levels hold 1, <= 8, <= 64, ... nodes; a launch per level costs ~25 us of dependent-load latency each however
+// few nodes it has.  One workgroup walks the levels that fit its threads, one node per thread, and leaves the first
+// level it did not do in *first_level (k_wide_level skips the earlier ones).  Everything it hands from one level to the
+// next (queue entries, level counts) stays inside the workgroup: workgroup-scope release / acquire around the barrier.
+constexpr uint32_t kWideTopThreads = 512;
+__global__ __launch_bounds__(kWideTopThreads) void k_wide_top(const float4 *pairs, const unsigned long long *choice, uint32_t *level_count, uint32_t max_levels,
+                                                              uint32_t *first_level, uint2 *q0, uint2 *q1, float4 *wide, uint32_t stride_f4) {
+    uint32_t next_base = 0, level = 0;
+    for (; level < max_levels; level++) {
+        const uint32_t n_in = __hip_atomic_load(&level_count[level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (n_in == 0u || n_in > kWideTopThreads) break;
+        next_base += n_in;
+        const uint2 *q_in = (level & 1u) ? q1 : q0;
+        uint2 *q_out = (level & 1u) ? q0 : q1;
+        if (threadIdx.x < n_in) {
+            const uint2 w = q_in[threadIdx.x];
+            wide_emit(pairs, choice, level, level_count, next_base, w.x, w.y, q_out, wide, stride_f4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    if (threadIdx.x == 0) *first_level = level;
+}
+
 __global__ void k_wide_init(uint32_t *level_count, uint32_t n_levels, uint2 *q0) {
     for (uint32_t i = threadIdx.x; i <= n_levels; i += blockDim.x) level_count[i] = i == 0 ? 1u : 0u;
     if (threadIdx.x == 0) q0[0] = make_uint2(0u, 0u);       // pair 0 -> wide node 0
@@ -334,45 +358,40 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
     // every wide node consumes at least one pair, so n_pairs bounds the node count and every level's queue
     if (!ensure_w(st.wide, (size_t)st.n_pairs * kWideStrideF4 * sizeof(float4), err)) return false;
     if (!ensure_w(st.wide_queue[0], (size_t)st.n_pairs * 8, err) || !ensure_w(st.wide_queue[1], (size_t)st.n_pairs * 8, err)) return false;
-    if (!ensure_w(st.wide_levels_dev, (kWideMaxLevels + 2) * 4, err)) return false;
+    if (!ensure_w(st.wide_levels_dev, (kWideMaxLevels + 3) * 4, err)) return false;
     uint32_t *lc = (uint32_t *)st.wide_levels_dev.ptr;
-    // ---- the table: parents -> depths -> buckets -> one launch per depth, deepest first --------------------------------
+    // ---- the table (only when the pairs' depths were measured, i.e. after the SAH refinement: the per-frame LBVH rebuild
+    // keeps the cheaper greedy rule): buckets by depth -> one launch per depth, deepest first ------------------------------
     static const bool greedy = [] { const char *e = getenv("CRT_WIDE_GREEDY"); return e && atoi(e) != 0; }();
     const unsigned long long *choice = nullptr;
-    if (!greedy && st.n_pairs > 1) {
-        const uint32_t np = st.n_pairs, halves = 2 * np;
-        if (!ensure_w(st.dp_cost, (size_t)np * 7 * 4, err) || !ensure_w(st.dp_choice, (size_t)np * 8, err) || !ensure_w(st.dp_parent, (size_t)np * 4, err) ||
-            !ensure_w(st.dp_depth, (size_t)np * 4, err) || !ensure_w(st.dp_list, (size_t)np * 4, err) || !ensure_w(st.dp_hist, 2 * kDpLevels * 4, err)) return false;
-        uint32_t *hist = (uint32_t *)st.dp_hist.ptr, *cursor = hist + kDpLevels;
-        HIP_TRY(hipMemsetAsync(st.dp_parent.ptr, 0xFF, (size_t)np * 4, stream));
-        HIP_TRY(hipMemsetAsync(hist, 0, 2 * kDpLevels * 4, stream));
-        hipLaunchKernelGGL(k_dp_parents, dim3((halves + 255) / 256), dim3(256), 0, stream, halves, (const float4 *)st.pairs.ptr, (uint32_t *)st.dp_parent.ptr);
-        hipLaunchKernelGGL(k_dp_depth, dim3((np + 255) / 256), dim3(256), 0, stream, np, (const uint32_t *)st.dp_parent.ptr, (uint32_t *)st.dp_depth.ptr, hist);
-        uint32_t host_hist[kDpLevels];
-        HIP_TRY(hipMemcpyAsync(host_hist, hist, kDpLevels * 4, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+    if (!greedy && st.levels_measured && st.n_pairs > 1) {
+        const uint32_t np = st.n_pairs;
+        if (!ensure_w(st.dp_cost, (size_t)np * 7 * 4, err) || !ensure_w(st.dp_choice, (size_t)np * 8, err) || !ensure_w(st.dp_list, (size_t)np * 4, err)) return false;
+        uint32_t *cursor = (uint32_t *)st.dp_hist.ptr + kDpLevels;      // zeroed by measure_pair_depths
         DpLevels lv; lv.start[0] = 0; lv.start[1] = 0;
-        uint32_t deepest = 0;
-        for (uint32_t d = 1; d < kDpLevels; d++) { lv.start[d + 1] = lv.start[d] + host_hist[d]; if (host_hist[d]) deepest = d; }
+        for (uint32_t d = 1; d < kDpLevels; d++) lv.start[d + 1] = lv.start[d] + st.level_hist[d];
         hipLaunchKernelGGL(k_dp_scatter, dim3((np + 255) / 256), dim3(256), 0, stream, np, (const uint32_t *)st.dp_depth.ptr, lv, cursor, (uint32_t *)st.dp_list.ptr);
-        for (uint32_t d = deepest; d >= 1; d--)
-            if (host_hist[d]) hipLaunchKernelGGL(k_dp_level, dim3((host_hist[d] + 127) / 128), dim3(128), 0, stream, (const float4 *)st.pairs.ptr, (const uint32_t *)st.dp_list.ptr,
-                               lv.start[d], host_hist[d], (float *)st.dp_cost.ptr, (unsigned long long *)st.dp_choice.ptr);
+        for (uint32_t d = st.pair_depth; d >= 1; d--)
+            if (st.level_hist[d]) hipLaunchKernelGGL(k_dp_level, dim3((st.level_hist[d] + 127) / 128), dim3(128), 0, stream, (const float4 *)st.pairs.ptr, (const uint32_t *)st.dp_list.ptr,
+                               lv.start[d], st.level_hist[d], (float *)st.dp_cost.ptr, (unsigned long long *)st.dp_choice.ptr);
         HIP_TRY(hipGetLastError());
         choice = (const unsigned long long *)st.dp_choice.ptr;
     }
     hipLaunchKernelGGL(k_wide_init, dim3(1), dim3(128), 0, stream, lc, kWideMaxLevels + 1, (uint2 *)st.wide_queue[0].ptr);
+    uint32_t *first_level = lc + kWideMaxLevels + 2;
+    hipLaunchKernelGGL(k_wide_top, dim3(1), dim3(kWideTopThreads), 0, stream, (const float4 *)st.pairs.ptr, choice, lc, kWideMaxLevels, first_level,
+                       (uint2 *)st.wide_queue[0].ptr, (uint2 *)st.wide_queue[1].ptr, (float4 *)st.wide.ptr, kWideStrideF4);
     const uint32_t grid = std::min<uint32_t>(2048u, (st.n_pairs + 127u) / 128u);
-    uint32_t host_lc[kWideMaxLevels + 2];
-    uint32_t level = 0;
+    uint32_t host_lc[kWideMaxLevels + 3];
+    uint32_t level = 1;      // k_wide_top always does level 0 (one node)
     for (;;) {
         const uint32_t chunk_end = std::min<uint32_t>(level + 8u, kWideMaxLevels);
         for (; level < chunk_end; level++)
-            hipLaunchKernelGGL(k_wide_level, dim3(grid), dim3(128), 0, stream, (const float4 *)st.pairs.ptr, choice, level, lc,
+            hipLaunchKernelGGL(k_wide_level, dim3(grid), dim3(128), 0, stream, (const float4 *)st.pairs.ptr, choice, level, lc, (const uint32_t *)first_level,
                                (const uint2 *)st.wide_queue[level & 1].ptr, (uint2 *)st.wide_queue[(level & 1) ^ 1].ptr,
                                (float4 *)st.wide.ptr, kWideStrideF4);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(host_lc, lc, (kWideMaxLevels + 2) * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(host_lc, lc, (kWideMaxLevels + 3) * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (host_lc[level] == 0) break;
         if (level >= kWideMaxLevels) { err = "wide BVH deeper than 64 levels"; return false; }
