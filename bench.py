@@ -288,7 +288,7 @@ def main():
     rays = float(st.rays)
     kernel_ms = st.last_render_ms     # HIP events on the context's stream around the timed launches (last run() call)
 
-    gather_ms = None
+    gather_ms, gather_path, gather_check = None, None, None
     if dist is not None:
         import torch
         tdev = torch.device("cpu") if rehearse else torch.device("cuda", local_rank)
@@ -297,15 +297,47 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed, rays = float(tmax[0]), float(t[1])
-        # gather the finished image: one all-gather of the packed band buffers + un-interleave (dist.py)
-        from computeraytracer_amd import dist as cdist
-        band = cdist.context_band_tensor(ctx, W, torch.device("cuda", local_rank)).to(tdev)
-        torch.cuda.synchronize(); dist.barrier()
-        g0 = time.perf_counter()
-        image = cdist.gather_image(band, H, world)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        assert tuple(image.shape) == (H, W, 4)
+        # gather the finished image: ONE all-gather of the packed band buffers + un-interleave, outside `value`
+        gather_path = "rccl-native"
+        if rehearse:
+            # gloo rehearsal on one GPU (RCCL refuses two ranks per device): the torch plumbing of dist.py
+            gather_path = "torch-gloo-rehearsal"
+            from computeraytracer_amd import dist as cdist
+            band = cdist.context_band_tensor(ctx, W, torch.device("cuda", local_rank)).to(tdev)
+            torch.cuda.synchronize(); dist.barrier()
+            g0 = time.perf_counter()
+            image = cdist.gather_image(band, H, world)
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+            assert tuple(image.shape) == (H, W, 4)
+            full = image.cpu().numpy()
+        else:
+            # the product path: crt_comm_init + crt_image_gather inside libcrt.so (csrc/dist/gather_rccl.hip); torch.distributed
+            # only carries the 128-byte communicator id from rank 0 to the others
+            idt = torch.zeros(abi.COMM_ID_BYTES, dtype=torch.uint8, device=tdev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(abi.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+            ctx.image_gather(); ctx.sync()            # the first collective on a communicator sets its channels up: untimed
+            torch.cuda.synchronize(); dist.barrier()
+            g0 = time.perf_counter()
+            ctx.image_gather(); ctx.sync()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+            full = ctx.image_gathered()
+            ctx.comm_destroy()
+        # every rank's bands arrived: each pixel of the rendered grid carries the last iteration's number in .w, and
+        # this rank's own rows are the ones it rendered
+        last_iter = float((args.warmup + args.steps) * spp) if not rebuild else 1.0
+        own = abi.band_rows(H, rank, world)
+        gh, gw = (H // 8) * 8, (W // 8) * 8
+        ok = bool((full[:gh, :gw, 3] == last_iter).all()) and bool(np.array_equal(full[own], ctx.image()[own]))
+        okt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=tdev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        gather_check = "ok" if float(okt[0]) == 1.0 else "MISMATCH"
+        gt = torch.tensor([gather_ms], dtype=torch.float64, device=tdev)
+        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+        gather_ms = float(gt[0])
 
     if rank == 0:
         mrays = rays / elapsed / 1e6
@@ -334,6 +366,7 @@ def main():
                        "tris": int(len(scene.tris)), "spheres": int(len(scene.spheres)), "quads": int(len(scene.quads)),
                        "tracer": args.tracer, "bvh": args.bvh, "rng": "ref-hash", "parallelism": f"tile{world}" if world > 1 else "single",
                        "bvh_build_ms": round(build_ms, 4), "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+                       "gather": gather_path, "gather_check": gather_check,
                        "rays_per_path": round(D, 3), "nodes_per_ray": round(V, 2), "prim_tests_per_ray": round(T, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),

@@ -102,6 +102,12 @@ def _load():
         "crt_image_device_ptr": (i32, [vp, P(vp), P(C.c_size_t)]),
         "crt_image_copy_to_device": (i32, [vp, vp, C.c_size_t]),
         "crt_band_rows": (u32, [u32, u32, u32, vp]),
+        "crt_comm_unique_id": (i32, [vp]),
+        "crt_comm_init": (i32, [vp, vp, u32, u32]),
+        "crt_comm_destroy": (i32, [vp]),
+        "crt_image_gather": (i32, [vp, vp]),
+        "crt_image_gathered_read": (i32, [vp, vp, C.c_size_t]),
+        "crt_bands_assemble": (i32, [vp, vp, u32, u32, u32, vp]),
         "crt_stats_read": (i32, [vp, P(Stats)]),
         "crt_stats_reset": (i32, [vp]),
         "crt_set_instrumented": (i32, [vp, i32]),
@@ -164,6 +170,18 @@ def make_quad(corner, u, v, material):
     out = np.zeros(1, dtype=quad_dtype)
     lib.crt_quad_init(_ptr(out), _f3(corner), _f3(u), _f3(v), material)
     return out
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """crt_comm_unique_id: the opaque 128-byte id rank 0 distributes to the other ranks."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    rc = lib.crt_comm_unique_id(buf)
+    if rc != 0:
+        raise CrtError(f"crt_comm_unique_id failed ({rc}): RCCL could not be loaded")
+    return bytes(buf)
 
 
 def band_rows(height, rank, world):
@@ -359,6 +377,25 @@ class Context:
 
     def image_copy_to_device(self, device_ptr, n_bytes):
         self._check(lib.crt_image_copy_to_device(self._h, C.c_void_p(device_ptr), n_bytes), "crt_image_copy_to_device")
+
+    def comm_init(self, comm_id, rank, world):
+        """crt_comm_init: comm_id = the 128 bytes rank 0 got from comm_unique_id()."""
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
+        self._check(lib.crt_comm_init(self._h, buf, rank, world), "crt_comm_init")
+
+    def comm_destroy(self):
+        self._check(lib.crt_comm_destroy(self._h), "crt_comm_destroy")
+
+    def image_gather(self, full_dev_ptr=None):
+        self._check(lib.crt_image_gather(self._h, C.c_void_p(full_dev_ptr) if full_dev_ptr else None), "crt_image_gather")
+
+    def image_gathered(self):
+        out = np.zeros((self.cfg.height, self.cfg.width, 4), dtype=np.float32)
+        self._check(lib.crt_image_gathered_read(self._h, _ptr(out), out.size), "crt_image_gathered_read")
+        return out
+
+    def bands_assemble(self, gathered_dev_ptr, width, height, world, full_dev_ptr):
+        self._check(lib.crt_bands_assemble(self._h, C.c_void_p(gathered_dev_ptr), width, height, world, C.c_void_p(full_dev_ptr)), "crt_bands_assemble")
 
     def stats(self):
         s = Stats()

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "build_internal.h"
+#include "gather_internal.h"
 #include "crt/abi.h"
 
 using namespace crt;
@@ -34,6 +35,7 @@ struct crt_context {
     DeviceBuffer accum, hit_ids, stats;
     uint32_t grid_w = 0, grid_h = 0, n_local_bands = 0, local_rows = 0;
     WavefrontState wf;
+    GatherState gather;
     int instrumented = 0;
     double last_render_ms = 0.0, last_build_ms = 0.0, last_extend_ms = 0.0;
     uint64_t last_extend_launches = 0;
@@ -211,6 +213,7 @@ void crt_destroy(crt_context *ctx) {
         for (DeviceBuffer *b : all) release(*b);
         free_build_state(ctx->build);
         free_wavefront(ctx->wf);
+        comm_destroy(ctx->gather);
         for (auto &sl : ctx->slot) { e = hipEventDestroy(sl.start); e = hipEventDestroy(sl.stop); }
         e = hipEventDestroy(ctx->ev_build[0]); e = hipEventDestroy(ctx->ev_build[1]); e = hipStreamDestroy(ctx->stream); (void)e;
     }
@@ -245,9 +248,12 @@ int crt_configure(crt_context *ctx, const crt_config *cfg) {
     if (world == 1 && rows < cfg->height) rows = cfg->height;
     ctx->local_rows = rows;
     size_t px = (size_t)rows * cfg->width;
-    rc = alloc(ctx, ctx->accum, px * 16); if (rc) return rc;
+    // the allocation is padded to the rows of the rank that owns the most bands (rank 0): crt_image_gather all-gathers
+    // equal-sized buffers straight out of it; the padding rows stay zero
+    const size_t px_alloc = (size_t)gather_max_rows(cfg->height, world) * cfg->width;
+    rc = alloc(ctx, ctx->accum, (px_alloc > px ? px_alloc : px) * 16); if (rc) return rc;
     rc = alloc(ctx, ctx->hit_ids, px * 4); if (rc) return rc;
-    CTX_HIP(hipMemsetAsync(ctx->accum.ptr, 0, px * 16, ctx->stream));
+    CTX_HIP(hipMemsetAsync(ctx->accum.ptr, 0, (px_alloc > px ? px_alloc : px) * 16, ctx->stream));
     CTX_HIP(hipMemsetAsync(ctx->hit_ids.ptr, 0xFF, px * 4, ctx->stream));
     CTX_HIP(hipStreamSynchronize(ctx->stream));
     ctx->configured = true;
@@ -507,6 +513,58 @@ int crt_image_copy_to_device(crt_context *ctx, void *dst_device, size_t n_bytes)
         return fail(ctx, CRT_ERR_INVALID, "crt_image_copy_to_device: destination must hold exactly the band buffer");
     CTX_HIP(hipMemcpyAsync(dst_device, ctx->accum.ptr, n_bytes, hipMemcpyDeviceToDevice, ctx->stream));
     CTX_HIP(hipStreamSynchronize(ctx->stream));
+    return CRT_OK;
+}
+
+int crt_comm_unique_id(void *id) {
+    if (!id) return CRT_ERR_INVALID;
+    std::string err;
+    return comm_unique_id(id, err) ? CRT_OK : CRT_ERR_HIP;
+}
+
+int crt_comm_init(crt_context *ctx, const void *id, uint32_t rank, uint32_t world) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!id) return fail(ctx, CRT_ERR_INVALID, "crt_comm_init: null id");
+    std::string err;
+    if (!comm_init(ctx->gather, id, rank, world, err)) return fail(ctx, CRT_ERR_HIP, "crt_comm_init: " + err);
+    return CRT_OK;
+}
+
+int crt_comm_destroy(crt_context *ctx) {
+    int rc = bind(ctx); if (rc) return rc;
+    CTX_HIP(hipStreamSynchronize(ctx->stream));
+    comm_destroy(ctx->gather);
+    return CRT_OK;
+}
+
+int crt_image_gather(crt_context *ctx, float *full_dev) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!ctx->configured) return fail(ctx, CRT_ERR_INVALID, "crt_image_gather: not configured");
+    const uint32_t world = ctx->cfg.band_world > 1 ? ctx->cfg.band_world : 1, rank = ctx->cfg.band_world > 1 ? ctx->cfg.band_rank : 0;
+    if (!ctx->gather.comm) return fail(ctx, CRT_ERR_INVALID, "crt_image_gather: crt_comm_init has not been called");
+    if (ctx->gather.world != world || ctx->gather.rank != rank)
+        return fail(ctx, CRT_ERR_INVALID, "crt_image_gather: the communicator's rank/world differ from crt_config.band_rank/band_world");
+    std::string err;
+    if (!full_dev && !gather_full_buffer(ctx->gather, ctx->cfg.width, ctx->cfg.height, &full_dev, err)) return fail(ctx, CRT_ERR_HIP, "crt_image_gather: " + err);
+    if (!gather_image(ctx->stream, ctx->gather, (const float *)ctx->accum.ptr, ctx->cfg.width, ctx->cfg.height, full_dev, err))
+        return fail(ctx, CRT_ERR_HIP, "crt_image_gather: " + err);
+    return CRT_OK;
+}
+
+int crt_image_gathered_read(crt_context *ctx, float *rgba, size_t n_floats) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!ctx->configured || !ctx->gather.full.ptr) return fail(ctx, CRT_ERR_INVALID, "crt_image_gathered_read: crt_image_gather(ctx, NULL) has not been called");
+    if (!rgba || n_floats != (size_t)ctx->cfg.width * ctx->cfg.height * 4) return fail(ctx, CRT_ERR_INVALID, "crt_image_gathered_read: buffer must hold width*height*4 floats");
+    CTX_HIP(hipStreamSynchronize(ctx->stream));
+    CTX_HIP(hipMemcpy(rgba, ctx->gather.full.ptr, n_floats * 4, hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt_bands_assemble(crt_context *ctx, const float *gathered_dev, uint32_t width, uint32_t height, uint32_t world, float *full_dev) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!gathered_dev || !full_dev || width == 0 || height == 0 || world == 0) return fail(ctx, CRT_ERR_INVALID, "crt_bands_assemble: null buffer or empty frame");
+    std::string err;
+    if (!bands_assemble(ctx->stream, gathered_dev, full_dev, width, height, world, err)) return fail(ctx, CRT_ERR_HIP, "crt_bands_assemble: " + err);
     return CRT_OK;
 }
 

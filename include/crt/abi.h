@@ -142,6 +142,26 @@ int crt_image_device_ptr(crt_context *ctx, void **device_ptr, size_t *n_bytes);
 /* Copies the packed band buffer into caller-owned device memory (e.g. a torch
  * tensor that RCCL will gather) and waits for the copy. */
 int crt_image_copy_to_device(crt_context *ctx, void *dst_device, size_t n_bytes);
+/* ---- multi-GPU gather; the reference is single-GPU (vk_engine.cpp:156-157), so none of these has a
+ * counterpart there.  One process per GPU; each renders its bands (crt_config.band_rank / band_world) and the finished
+ * frame is assembled with ONE all-gather over RCCL (xGMI) + an un-interleave kernel.  RCCL is bound at run time
+ * (dlopen of librccl.so.1), libcrt.so has no link-time dependency on it.
+ *   crt_comm_unique_id   rank 0 makes the id (ncclGetUniqueId) and hands its CRT_COMM_ID_BYTES bytes to the other ranks
+ *                        by whatever channel the engine has (a socket, MPI, a file; the bench uses torch.distributed);
+ *   crt_comm_init        collective over all ranks (ncclCommInitRank) on the context's GPU;
+ *   crt_image_gather     enqueues the all-gather of the packed band buffers and the un-interleave on the context's
+ *                        stream; full_dev = device buffer of width*height*4 floats that receives the whole frame on
+ *                        every rank (NULL: a buffer owned by the context, read with crt_image_gathered_read);
+ *                        crt_sync waits.  rank/world must be the ones given to crt_configure;
+ *   crt_bands_assemble   only the un-interleave: gathered_dev = world buffers of ceil(ceil(height/8)/world)*8 rows,
+ *                        rank-major (what the all-gather produces), for engines that move the bands themselves. */
+int crt_comm_unique_id(void *id /* CRT_COMM_ID_BYTES */);
+int crt_comm_init(crt_context *ctx, const void *id, uint32_t rank, uint32_t world);
+int crt_comm_destroy(crt_context *ctx);
+int crt_image_gather(crt_context *ctx, float *full_dev);
+int crt_image_gathered_read(crt_context *ctx, float *rgba, size_t n_floats);
+int crt_bands_assemble(crt_context *ctx, const float *gathered_dev, uint32_t width, uint32_t height, uint32_t world, float *full_dev);
+
 /* Rows owned by (band_rank, band_world) for a given height: writes the y of
  * each owned row in increasing order; returns the count (rows may be NULL). */
 uint32_t crt_band_rows(uint32_t height, uint32_t band_rank, uint32_t band_world, uint32_t *rows);

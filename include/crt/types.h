@@ -140,6 +140,9 @@ enum {
     CRT_QUERY_ANY = 1       /* shadow rays: id != CRT_ID_MISS iff SOME primitive is hit in the interval; which one is unspecified */
 };
 
+/* crt_comm_unique_id / crt_comm_init: size of the opaque communicator id (= NCCL_UNIQUE_ID_BYTES). */
+#define CRT_COMM_ID_BYTES 128
+
 /* crt_rays_query_noalloc: most rays one call takes (its queue lives in a static device array of
  * 32 bytes per ray + 128 KiB of counters = 4.125 MiB per GPU). */
 #define CRT_NOALLOC_MAX_RAYS 131072u

@@ -798,3 +798,44 @@ def test_dispatch_does_not_wait_for_the_gpu(ctx):
     ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
     ctx.render(ps[0], 1, seeds); ctx.sync()
     assert np.array_equal(a.view(np.uint32), ctx.image().view(np.uint32))
+
+
+def test_native_gather_world_1_and_band_assembly(ctx):
+    """crt_comm_* / crt_image_gather (RCCL bound at run time) with a single rank: init, one all-gather, un-interleave, destroy;
+    and the un-interleave kernel alone against the numpy statement of the band layout (dist.pack_bands) for 2, 3 and 8 ranks."""
+    from computeraytracer_amd import dist as cdist
+    from hip_util import Hip
+    w, h, n = 104, 50, 2                                  # ragged height: 7 bands, the last one 2 rows
+    scene = abi.builtin_scene("corne", w, h)
+    img, ids, ps = _gpu_render(ctx, scene, w, h, n, flags=abi.FLAG_FULL_IMAGE, tracer=abi.TRACER_WAVEFRONT)
+    cid = abi.comm_unique_id()
+    assert len(cid) == abi.COMM_ID_BYTES and any(cid)
+    ctx.comm_init(cid, 0, 1)
+    try:
+        with pytest.raises(abi.CrtError, match="already"):
+            ctx.comm_init(cid, 0, 1)
+        ctx.image_gather(); ctx.sync()
+        assert np.array_equal(ctx.image_gathered().view(np.uint32), img.view(np.uint32))
+    finally:
+        ctx.comm_destroy()
+    with pytest.raises(abi.CrtError, match="crt_comm_init has not been called"):
+        ctx.image_gather()
+    hip = Hip()
+    rs = np.random.RandomState(2)
+    for world, hh, ww in [(2, 64, 24), (3, 100, 16), (8, 2160, 8), (8, 225, 40)]:
+        full = rs.random_sample((hh, ww, 4)).astype(np.float32)
+        max_rows = cdist.local_rows(hh, 0, world)
+        cat = np.zeros((world * max_rows, ww, 4), np.float32)
+        for r in range(world):
+            b = cdist.pack_bands(full, r, world)
+            cat[r * max_rows:r * max_rows + b.shape[0]] = b
+        assert np.array_equal(cat[cdist.row_index(hh, world, max_rows)], full)        # dist.py's own inverse
+        d_in, d_out = hip.malloc(cat.nbytes), hip.malloc(full.nbytes)
+        try:
+            hip.h2d(d_in, cat)
+            ctx.bands_assemble(d_in, ww, hh, world, d_out); ctx.sync()
+            got = np.zeros_like(full)
+            hip.d2h(got, d_out)
+        finally:
+            hip.free(d_in); hip.free(d_out)
+        assert np.array_equal(got, full), (world, hh, ww)

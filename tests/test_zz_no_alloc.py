@@ -1,8 +1,6 @@
 """crt_rays_query_noalloc (the entry point that allocates nothing) against crt_rays_query, through the C ABI.
 
 Collected last on purpose (file name): the round's end runs pytest -x."""
-import ctypes as C
-
 import numpy as np
 import pytest
 
@@ -11,33 +9,7 @@ from computeraytracer_amd import abi
 pytestmark = pytest.mark.gpu
 
 
-class _Hip:
-    """hipMalloc / hipMemcpy / hipFree of the HIP runtime libcrt.so is already bound to (same soname, same copy): the
-    caller's device buffers.  Test plumbing only."""
-
-    def __init__(self):
-        self.lib = C.CDLL("libamdhip64.so.7")
-        self.lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-        self.lib.hipFree.argtypes = [C.c_void_p]
-        self.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        self.lib.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
-
-    def malloc(self, n):
-        p = C.c_void_p()
-        assert self.lib.hipMalloc(C.byref(p), n) == 0
-        return p.value
-
-    def free(self, p):
-        assert self.lib.hipFree(C.c_void_p(p)) == 0
-
-    def h2d(self, dst, a):
-        assert self.lib.hipMemcpy(C.c_void_p(dst), a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0
-
-    def d2h(self, a, src):
-        assert self.lib.hipMemcpy(a.ctypes.data_as(C.c_void_p), C.c_void_p(src), a.nbytes, 2) == 0
-
-    def memset(self, p, v, n):
-        assert self.lib.hipMemset(C.c_void_p(p), v, n) == 0
+from hip_util import Hip as _Hip
 
 
 def _rays(scene, n, seed):
