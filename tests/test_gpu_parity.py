@@ -839,3 +839,61 @@ def test_native_gather_world_1_and_band_assembly(ctx):
         finally:
             hip.free(d_in); hip.free(d_out)
         assert np.array_equal(got, full), (world, hh, ww)
+
+
+def _engine_binding_exe():
+    """tests/bin/engine_binding_main: built by __graft_entry__.build(); compiled here if it is missing (g++ only, seconds)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "bin", "engine_binding_main")
+    src = os.path.join(root, "tests", "engine_binding_main.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        libdir = os.path.join(root, "computeraytracer_amd", "lib")
+        r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), src, "-L", libdir, "-lcrt",
+                            "-Wl,-rpath,$ORIGIN/../../computeraytracer_amd/lib", "-o", exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    return exe
+
+
+@pytest.mark.parametrize("name,w,h,frames", [("corne", 96, 96, 5), ("mixed", 160, 88, 4)])
+def test_engine_binding_program_matches_the_oracle(tmp_path, name, w, h, frames):
+    """SURVEY 8(f) row 4 as far as it can be built without Vulkan: a C++ program that keeps the scene the way VulkanEngine
+    does and runs INTEGRATION.md's binding code (flatten<U> over std::vector<std::any>, reinterpret_cast of GPUSceneData,
+    rand() / 1E3f seeds, one crt_dispatch per frame) against libcrt.so.  Its image must be the oracle's, bit for bit."""
+    import struct
+    import subprocess
+    out = str(tmp_path / "engine.bin")
+    r = subprocess.run([_engine_binding_exe(), name, str(w), str(h), str(frames), out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    blob, pos, got = open(out, "rb").read(), 0, {}
+    while pos < len(blob):
+        tag = blob[pos:pos + 8].decode().strip()
+        (n,) = struct.unpack_from("<Q", blob, pos + 8)
+        got.setdefault(tag, []).append(blob[pos + 16:pos + 16 + n])
+        pos += 16 + n
+    seeds = np.frombuffer(got["seeds"][0], np.float32)
+    # vk_engine.cpp:1412 draws the frame seed from libc rand(), which the reference never seeds; in this process the HIP
+    # runtime has used rand()/srand() before the first frame, so the values are not crt_frame_seeds' (glibc, seed 1) and
+    # the oracle is given the seeds the program actually used: any seed schedule is a valid run of the reference
+    assert len(seeds) == frames and np.isfinite(seeds).all() and (seeds >= 0).all() and (seeds <= 2147483.7).all() and len(set(seeds.tolist())) == frames
+    textures = []
+    for dims, px in zip(got.get("texdims", []), got.get("texture", [])):
+        tw, th = struct.unpack("<II", dims)
+        textures.append(np.frombuffer(px, np.uint8).reshape(th, tw, 4))
+    scene = abi.HostScene(spheres=np.frombuffer(got["sphere"][0], abi.sphere_dtype), quads=np.frombuffer(got["quad"][0], abi.quad_dtype),
+                          tris=np.frombuffer(got["tri"][0], abi.tri_dtype), materials=np.frombuffer(got["material"][0], abi.material_dtype),
+                          textures=textures, params=np.frombuffer(got["params"][0], abi.params_dtype).copy(), name="engine-" + name)
+    if name == "corne":
+        ref_scene = abi.builtin_scene("corne", w, h)
+        assert scene.quads.tobytes() == ref_scene.quads.tobytes() and scene.materials.tobytes() == ref_scene.materials.tobytes()
+    ps = [scene.params_for(i + 1, seeds[i]) for i in range(frames)]
+    ref_img, ref_ids, _ = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_BRUTE)
+    accum = np.frombuffer(got["accum"][0], np.float32).reshape(h, w, 4)
+    ids = np.frombuffer(got["ids"][0], np.uint32).reshape(h, w)
+    assert np.array_equal(ids, ref_ids)
+    assert np.array_equal(accum.view(np.uint32), ref_img.view(np.uint32))
+    assert (accum[..., 3] == frames).all() and (ref_ids != abi.ID_MISS).mean() > 0.3
+    presented = np.frombuffer(got["present"][0], np.float32).reshape(h, w, 3)
+    assert np.array_equal(presented, (ref_img[..., :3] / ref_img[..., 3:4])[::-1])      # compute.frag:15-16: rgb / w, V flip
