@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -117,9 +119,17 @@ static bool load_binaryfile(const std::string &path, AssetFile &f, std::string &
     uint32_t hdr[3];
     bool ok = fread(f.type, 1, 4, fp) == 4 && fread(hdr, 4, 3, fp) == 3;
     if (ok) {
+        // the header's sizes are checked against what the file really holds before anything is allocated from them
+        long here = ftell(fp), end = -1;
+        if (here >= 0 && fseek(fp, 0, SEEK_END) == 0) end = ftell(fp);
+        if (end < here || fseek(fp, here, SEEK_SET) != 0 || (uint64_t)hdr[1] + (uint64_t)hdr[2] > (uint64_t)(end - here)) {
+            fclose(fp);
+            err = "asset header of " + path + " claims more bytes than the file has";
+            return false;
+        }
         f.version = hdr[0];
         f.json.resize(hdr[1]); f.blob.resize(hdr[2]);
-        ok = fread(&f.json[0], 1, hdr[1], fp) == hdr[1] && fread(f.blob.data(), 1, hdr[2], fp) == hdr[2];
+        ok = (hdr[1] == 0 || fread(&f.json[0], 1, hdr[1], fp) == hdr[1]) && (hdr[2] == 0 || fread(f.blob.data(), 1, hdr[2], fp) == hdr[2]);
     }
     fclose(fp);
     if (!ok) err = "truncated asset file " + path;
@@ -145,8 +155,14 @@ static bool load_obj(const std::string &path, std::vector<MeshVertex> &out, std:
     FILE *fp = fopen(path.c_str(), "r");
     if (!fp) { err = "cannot open " + path; return false; }
     std::vector<float> pos, nor, tex;
-    char line[1024];
-    while (fgets(line, sizeof line, fp)) {
+    std::string text;                                  // one line of any length (a face of a large polygon does not fit a fixed buffer)
+    for (;;) {
+        text.clear();
+        int ch;
+        while ((ch = fgetc(fp)) != EOF && ch != '\n') text.push_back((char)ch);
+        if (ch == EOF && text.empty()) break;
+        text.push_back('\n');
+        char *line = &text[0];
         char *p = line;
         while (*p == ' ' || *p == '\t') p++;
         if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
@@ -192,6 +208,12 @@ static bool load_obj(const std::string &path, std::vector<MeshVertex> &out, std:
     return true;
 }
 
+// A byte count read from an asset's JSON: finite, >= 0, a whole number of `elem`-byte elements, at most INT_MAX.
+static bool valid_size(double v, size_t elem) {
+    if (!(v >= 0.0) || !(v <= 2147483647.0) || v != std::floor(v)) return false;      // also rejects NaN
+    return (size_t)v % elem == 0;
+}
+
 // mesh_asset.cpp:15-57 + vk_mesh.cpp:28-90
 static bool load_mesh_container(const std::string &path, std::vector<MeshVertex> &verts, std::vector<uint32_t> &indices, std::string &err) {
     AssetFile f;
@@ -202,6 +224,10 @@ static bool load_mesh_container(const std::string &path, std::vector<MeshVertex>
         !json_string(f.json, "vertex_format", fmt)) { err = path + ": missing mesh metadata"; return false; }
     if (fmt != "PNCV_F32") { err = path + ": unsupported vertex_format " + fmt; return false; }
     json_string(f.json, "compression", comp);
+    // sizes come from the file: finite, non-negative, whole elements, and within what the int-based LZ4 codec can address
+    if (!valid_size(vbs, sizeof(MeshVertex)) || !valid_size(ibs, 4) || vbs + ibs > 2147483647.0 || f.blob.size() > 2147483647u) {
+        err = path + ": vertex_buffer_size / index_buffer_size out of range"; return false;
+    }
     std::vector<uint8_t> raw((size_t)vbs + (size_t)ibs);
     if (comp == "LZ4") {
         if (lz4_decompress(f.blob.data(), (int)f.blob.size(), raw.data(), (int)raw.size()) != (int)raw.size()) { err = path + ": LZ4 stream corrupt"; return false; }
@@ -234,6 +260,9 @@ bool load_texture_file(const std::string &path, std::vector<uint8_t> &rgba, uint
     double ww = 0, hh = 0, bs = 0; std::string fmt, comp;
     if (!json_number(f.json, "width", ww) || !json_number(f.json, "height", hh) || !json_number(f.json, "buffer_size", bs) ||
         !json_string(f.json, "format", fmt)) { err = path + ": missing texture metadata"; return false; }
+    if (!valid_size(ww, 1) || !valid_size(hh, 1) || !valid_size(bs, 4) || ww < 1.0 || hh < 1.0 || ww > 65536.0 || hh > 65536.0 || f.blob.size() > 2147483647u) {
+        err = path + ": width / height / buffer_size out of range"; return false;
+    }
     if (fmt != "RGBA8" || (size_t)bs != (size_t)ww * (size_t)hh * 4) { err = path + ": unsupported texture"; return false; }
     json_string(f.json, "compression", comp);
     rgba.resize((size_t)bs);
@@ -251,6 +280,14 @@ bool load_texture_file(const std::string &path, std::vector<uint8_t> &rgba, uint
 
 using namespace crt;
 
+// Nothing may leave an extern "C" entry point as an exception: an allocation sized from a (validated, but possibly large)
+// file, or any other failure inside the readers, becomes CRT_ERR_IO with a message.
+template <typename F> static int guarded(F &&f) {
+    try { return f(); }
+    catch (const std::bad_alloc &) { set_host_error("out of memory while reading an asset"); return CRT_ERR_IO; }
+    catch (const std::exception &e) { set_host_error(e.what()); return CRT_ERR_IO; }
+}
+
 extern "C" {
 
 int crt_lz4_compress_bound(int n) { return lz4_bound(n); }
@@ -258,15 +295,18 @@ int crt_lz4_compress(const uint8_t *src, int n, uint8_t *dst, int cap) { int r =
 int crt_lz4_decompress(const uint8_t *src, int n, uint8_t *dst, int cap) { int r = lz4_decompress(src, n, dst, cap); return r < 0 ? CRT_ERR_IO : r; }
 
 int crt_obj_to_vertices(const char *path, float **vertices_pncv, uint32_t *n_vertices) {
+    return guarded([&]() -> int {
     std::vector<MeshVertex> v; std::string err;
     if (!load_obj(path, v, err)) { set_host_error(err); return CRT_ERR_IO; }
     *vertices_pncv = (float *)malloc(v.size() * sizeof(MeshVertex) + 1);
     memcpy(*vertices_pncv, v.data(), v.size() * sizeof(MeshVertex));
     *n_vertices = (uint32_t)v.size();
     return CRT_OK;
+    });
 }
 
 int crt_load_obj(const char *path, uint32_t material_index, crt_tri **tris, uint32_t *n_tris) {
+    return guarded([&]() -> int {
     std::vector<MeshVertex> v; std::string err;
     if (!load_mesh_file(path, v, err)) { set_host_error(err); return CRT_ERR_IO; }
     uint32_t n = (uint32_t)(v.size() / 3);
@@ -280,9 +320,11 @@ int crt_load_obj(const char *path, uint32_t material_index, crt_tri **tris, uint
     }
     *tris = t; *n_tris = n;
     return CRT_OK;
+    });
 }
 
 int crt_mesh_file_read(const char *path, float **vertices_pncv, uint32_t *n_vertices, uint32_t **indices, uint32_t *n_indices) {
+    return guarded([&]() -> int {
     std::vector<MeshVertex> v; std::vector<uint32_t> idx; std::string err;
     if (!load_mesh_container(path, v, idx, err)) { set_host_error(err); return CRT_ERR_IO; }
     *vertices_pncv = (float *)malloc(v.size() * sizeof(MeshVertex) + 1);
@@ -291,11 +333,13 @@ int crt_mesh_file_read(const char *path, float **vertices_pncv, uint32_t *n_vert
     memcpy(*indices, idx.data(), idx.size() * 4);
     *n_vertices = (uint32_t)v.size(); *n_indices = (uint32_t)idx.size();
     return CRT_OK;
+    });
 }
 
 // mesh_asset.cpp:60-152 (pack_mesh + calculate_bounds)
 int crt_mesh_file_write(const char *path, const float *vertices_pncv, uint32_t n_vertices, const uint32_t *indices,
                         uint32_t n_indices, const char *original_file) {
+    return guarded([&]() -> int {
     const MeshVertex *v = (const MeshVertex *)vertices_pncv;
     float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
     float mx[3] = {1.175494351e-38f, 1.175494351e-38f, 1.175494351e-38f};   // numeric_limits<float>::min() (sic, :118)
@@ -316,6 +360,7 @@ int crt_mesh_file_write(const char *path, const float *vertices_pncv, uint32_t n
     f.json += "\"original_file\":\"" + json_escape(original_file ? original_file : "") + "\",";
     snprintf(buf, sizeof buf, "\"vertex_buffer_size\":%zu,\"vertex_format\":\"PNCV_F32\"}", vbs);
     f.json += buf;
+    if (vbs + ibs > 2147483647u - 65536u) { set_host_error("mesh larger than the LZ4 block format addresses (2 GiB)"); return CRT_ERR_INVALID; }
     std::vector<uint8_t> merged(vbs + ibs);
     memcpy(merged.data(), vertices_pncv, vbs);
     memcpy(merged.data() + vbs, indices, ibs);
@@ -326,18 +371,22 @@ int crt_mesh_file_write(const char *path, const float *vertices_pncv, uint32_t n
     std::string err;
     if (!save_binaryfile(path, f, err)) { set_host_error(err); return CRT_ERR_IO; }
     return CRT_OK;
+    });
 }
 
 int crt_texture_file_read(const char *path, uint8_t **rgba8, uint32_t *width, uint32_t *height) {
+    return guarded([&]() -> int {
     std::vector<uint8_t> px; std::string err;
     if (!load_texture_file(path, px, *width, *height, err)) { set_host_error(err); return CRT_ERR_IO; }
     *rgba8 = (uint8_t *)malloc(px.size() + 1);
     memcpy(*rgba8, px.data(), px.size());
     return CRT_OK;
+    });
 }
 
 // texture_asset.cpp:12-43
 int crt_texture_file_write(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height, const char *original_file) {
+    return guarded([&]() -> int {
     AssetFile f; memcpy(f.type, "TEXI", 4); f.version = 1;
     size_t bs = (size_t)width * height * 4;
     char buf[256];
@@ -346,6 +395,7 @@ int crt_texture_file_write(const char *path, const uint8_t *rgba8, uint32_t widt
     f.json += "\"original_file\":\"" + json_escape(original_file ? original_file : "") + "\",";
     snprintf(buf, sizeof buf, "\"width\":%u}", width);
     f.json += buf;
+    if (bs > 2147483647u - 65536u) { set_host_error("texture larger than the LZ4 block format addresses (2 GiB)"); return CRT_ERR_INVALID; }
     f.blob.resize((size_t)lz4_bound((int)bs));
     int c = lz4_compress(rgba8, (int)bs, f.blob.data(), (int)f.blob.size());
     if (c < 0) { set_host_error("LZ4 compression failed"); return CRT_ERR_INVALID; }
@@ -353,6 +403,7 @@ int crt_texture_file_write(const char *path, const uint8_t *rgba8, uint32_t widt
     std::string err;
     if (!save_binaryfile(path, f, err)) { set_host_error(err); return CRT_ERR_IO; }
     return CRT_OK;
+    });
 }
 
 }  // extern "C"

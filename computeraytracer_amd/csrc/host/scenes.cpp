@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -304,7 +306,9 @@ extern "C" {
 
 int crt_scene_builtin(const char *name, const char *asset_dir, uint32_t width, uint32_t height, crt_host_scene **out) {
     if (!name || !out || width == 0 || height == 0) { set_host_error("crt_scene_builtin: bad argument"); return CRT_ERR_INVALID; }
-    crt_host_scene *s = new crt_host_scene();
+    crt_host_scene *s = new (std::nothrow) crt_host_scene();
+    if (!s) { set_host_error("crt_scene_builtin: out of memory"); return CRT_ERR_IO; }
+    try {
     SceneBuilder &b = s->b;
     // the window aspect overrides the scene's (vk_engine.cpp:731,1342)
     float aspect = (float)width / (float)height;
@@ -326,6 +330,11 @@ int crt_scene_builtin(const char *name, const char *asset_dir, uint32_t width, u
     b.finish();
     *out = s;
     return CRT_OK;
+    } catch (const std::exception &e) {      // bad_alloc from a scene or asset too large for the host: an error code, not an abort
+        set_host_error(std::string("crt_scene_builtin: ") + e.what());
+        delete s;
+        return CRT_ERR_IO;
+    }
 }
 
 const crt_scene_desc *crt_host_scene_desc(const crt_host_scene *s) { return &s->b.desc; }

@@ -194,3 +194,34 @@ def test_lost_empire_scene_uses_a_supplied_mesh(tmp_path):
     assert np.isfinite(cam["position"]).all() and cam["position"][1] > 1.0       # above the box, looking at its centre
     offs, prims, is_list = s.world
     assert list(offs) == [0, 1, 2] and not is_list.any()
+
+
+def test_asset_readers_reject_lying_headers_and_long_obj_lines(tmp_path):
+    """sizes read from a file must not drive allocations or casts unchecked; OBJ face lines may be long."""
+    import struct
+    # a header that claims 4 GiB of JSON + blob in a 16-byte file
+    bad = tmp_path / "huge.mesh"
+    bad.write_bytes(b"MESH" + struct.pack("<III", 1, 0xFFFFFFF0, 0xFFFFFFF0))
+    p, n, q, m = C.c_void_p(), C.c_uint32(), C.c_void_p(), C.c_uint32()
+    assert abi.lib.crt_mesh_file_read(os.fsencode(str(bad)), C.byref(p), C.byref(n), C.byref(q), C.byref(m)) == -4
+    assert b"claims more bytes" in abi.lib.crt_host_last_error()
+    # negative / fractional / non-finite buffer sizes in the JSON
+    for vbs in ("-44", "1e300", "43", "nan"):
+        js = ('{"compression":"None","index_buffer_size":0,"index_size":4,"original_file":"x","vertex_buffer_size":%s,"vertex_format":"PNCV_F32"}' % vbs).encode()
+        f = tmp_path / "bad.mesh"
+        f.write_bytes(b"MESH" + struct.pack("<III", 1, len(js), 0) + js)
+        assert abi.lib.crt_mesh_file_read(os.fsencode(str(f)), C.byref(p), C.byref(n), C.byref(q), C.byref(m)) == -4, vbs
+    js = b'{"buffer_size":-4,"compression":"None","format":"RGBA8","height":1,"original_file":"x","width":-1}'
+    t = tmp_path / "bad.tx"
+    t.write_bytes(b"TEXI" + struct.pack("<III", 1, len(js), 0) + js)
+    w, h = C.c_uint32(), C.c_uint32()
+    assert abi.lib.crt_texture_file_read(os.fsencode(str(t)), C.byref(p), C.byref(w), C.byref(h)) == -4
+    # an OBJ polygon whose 'f' line is far longer than any fixed line buffer: 2000 corners -> 1998 fan triangles, none dropped
+    k = 2000
+    ang = np.linspace(0, 2 * np.pi, k, endpoint=False)
+    obj = tmp_path / "fan.obj"
+    obj.write_text("".join(f"v {np.cos(a):.6f} {np.sin(a):.6f} 0\n" for a in ang) + "f " + " ".join(str(i + 1) for i in range(k)) + "\n")
+    assert os.path.getsize(obj) > 8000
+    tris = abi.load_obj(str(obj))
+    assert len(tris) == k - 2
+    assert np.allclose(tris["v0"], [1, 0, 0]) and np.allclose(tris["v2"][-1], [np.cos(ang[-1]), np.sin(ang[-1]), 0], atol=1e-6)
