@@ -30,6 +30,7 @@ struct BuildState {
     uint32_t sah_tiers = 0;
     // results (what traversal reads)
     DeviceBuffer pairs, tri_pack, sphere_pack, quad_pack, sphere_ids, quad_ids, tri_ids;
+    DeviceBuffer tri_shade;        // 64-byte shading record per triangle, input order (bvh_build.hip: write_tri_shade)
     // 8-wide quantised nodes (bvh_wide.hip, CRT_BVH_WIDE): n_wide nodes of kWideStrideF4 float4 each, BFS order
     DeviceBuffer wide, wide_queue[2], wide_levels_dev;
     DeviceBuffer dp_cost, dp_choice, dp_parent, dp_depth, dp_list, dp_hist;      // collapse table (bvh_wide.hip)
@@ -58,7 +59,7 @@ void free_build_state(BuildState &st);
 struct DeviceSceneHost {       // host-side mirror of DeviceScene (kept POD so context.hip need not include device headers)
     const void *nodes; uint32_t n_pairs;
     const void *wide; uint32_t n_wide, wide_levels;     // 8-wide nodes (null: the wavefront tracer walks the pair BVH)
-    const void *tri_pack, *sphere_pack, *quad_pack;
+    const void *tri_pack, *sphere_pack, *quad_pack, *tri_shade;
     const uint32_t *sphere_ids, *quad_ids;
     const crt_sphere *spheres; const crt_quad *quads; const crt_tri *tris;
     const crt_material *materials;

@@ -63,12 +63,29 @@ __device__ __forceinline__ void prim_box(const BuildInput &in, uint32_t g, float
     }
 }
 
-__global__ __launch_bounds__(256) void k_prim_bounds(BuildInput in, uint32_t n, float4 *plo, float4 *phi, uint32_t *scene_bounds) {
+// Shading record of triangle i (input order, 64 bytes = half a cache line, never straddling one): everything k_wf_shade
+// needs of a hit triangle in four 16-byte loads from ONE line: {v0.xyz, e10.x} {e10.yz, e20.xy} {e20.z, materialIndex,
+// u0, u1} {u2, v0, v1, v2}.  The 96-byte upload record put materialIndex 92 bytes after v0 (a second line for every
+// other triangle) and the shader's two edge subtractions in front of every hit; e10 / e20 are those same IEEE
+// subtractions (compute.comp:281-282), done once here.
+__device__ __forceinline__ void write_tri_shade(const BuildInput &in, uint32_t g, float4 *tri_shade) {
+    const uint32_t i = g - in.n_spheres - in.n_quads;
+    const float4 *p = (const float4 *)(in.tris + i);
+    const float4 v0 = p[0], v1 = p[1], v2 = p[2], tu = p[3], tv = p[4], last = p[5];
+    float4 *o = tri_shade + 4 * (size_t)i;
+    o[0] = make_float4(v0.x, v0.y, v0.z, v1.x - v0.x);
+    o[1] = make_float4(v1.y - v0.y, v1.z - v0.z, v2.x - v0.x, v2.y - v0.y);
+    o[2] = make_float4(v2.z - v0.z, last.w, tu.x, tu.y);
+    o[3] = make_float4(tu.z, tv.x, tv.y, tv.z);
+}
+
+__global__ __launch_bounds__(256) void k_prim_bounds(BuildInput in, uint32_t n, float4 *plo, float4 *phi, float4 *tri_shade, uint32_t *scene_bounds) {
     // grid-stride: the grid is capped (build_bvh) so that the atomics below stay a few thousand however large n is
     uint32_t cmn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, cmx[3] = {0u, 0u, 0u};
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
         float lo[3], hi[3];
         prim_box(in, g, lo, hi);
+        if (g >= in.n_spheres + in.n_quads) write_tri_shade(in, g, tri_shade);
         plo[g] = make_float4(lo[0], lo[1], lo[2], 0.0f);
         phi[g] = make_float4(hi[0], hi[1], hi[2], 0.0f);
         for (int a = 0; a < 3; a++) { const uint32_t e = enc_f(0.5f * lo[a] + 0.5f * hi[a]); cmn[a] = min(cmn[a], e); cmx[a] = max(cmx[a], e); }
@@ -468,6 +485,7 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     if (!ensure(st.quad_pack, (size_t)in.n_quads * 4 * sizeof(float4), err)) return false;
     if (!ensure(st.sphere_ids, (size_t)in.n_spheres * 4, err) || !ensure(st.quad_ids, (size_t)in.n_quads * 4, err)) return false;
     if (!ensure(st.tri_ids, (size_t)in.n_tris * 4, err)) return false;
+    if (!ensure(st.tri_shade, (size_t)in.n_tris * 4 * sizeof(float4), err)) return false;
 
     // temp storage for rocPRIM (sized for the larger of sort and scan)
     size_t sort_bytes = 0, scan_bytes = 0;
@@ -491,7 +509,7 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
 
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, (uint32_t *)st.scene_bounds.ptr);
     hipLaunchKernelGGL(k_prim_bounds, dim3(std::min(blocks, 4096u)), dim3(256), 0, stream, in, n, (float4 *)st.plo.ptr, (float4 *)st.phi.ptr,
-                       (uint32_t *)st.scene_bounds.ptr);
+                       (float4 *)st.tri_shade.ptr, (uint32_t *)st.scene_bounds.ptr);
     hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, bits, (const float4 *)st.plo.ptr, (const float4 *)st.phi.ptr,
                        (const uint32_t *)st.scene_bounds.ptr, (uint64_t *)st.keys.ptr, (uint32_t *)st.vals.ptr);
     HIP_TRY(hipGetLastError());
@@ -579,7 +597,7 @@ void free_build_state(BuildState &st) {
                            &st.rank_b, &st.leaf_link, &st.leaf_count, &st.child_l, &st.child_r, &st.parent, &st.nlo, &st.nhi, &st.ninfo,
                            &st.scene_bounds, &st.temp, &st.range_lo, &st.range_hi, &st.sah_flag, &st.sah_ipos[0],
                            &st.sah_ipos[1], &st.sah_starts, &st.sah_desc, &st.perm, &st.pairs, &st.tri_pack, &st.sphere_pack, &st.quad_pack, &st.sphere_ids,
-                           &st.quad_ids, &st.tri_ids, &st.wide, &st.wide_queue[0], &st.wide_queue[1], &st.wide_levels_dev,
+                           &st.quad_ids, &st.tri_ids, &st.tri_shade, &st.wide, &st.wide_queue[0], &st.wide_queue[1], &st.wide_levels_dev,
                            &st.dp_cost, &st.dp_choice, &st.dp_parent, &st.dp_depth, &st.dp_list, &st.dp_hist,
                            &st.refit_list[0], &st.refit_list[1], &st.refit_count[0], &st.refit_count[1]};
     for (DeviceBuffer *b : all) if (b->ptr) { hipError_t e = hipFree(b->ptr); (void)e; b->ptr = nullptr; b->bytes = 0; }

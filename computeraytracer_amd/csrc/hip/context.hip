@@ -82,6 +82,7 @@ DeviceSceneHost scene_view(const crt_context *ctx) {
     s.nodes = ctx->build.pairs.ptr; s.n_pairs = ctx->build.n_pairs;
     s.wide = ctx->build.n_wide ? ctx->build.wide.ptr : nullptr; s.n_wide = ctx->build.n_wide; s.wide_levels = ctx->build.wide_levels;
     s.tri_pack = ctx->build.tri_pack.ptr; s.sphere_pack = ctx->build.sphere_pack.ptr; s.quad_pack = ctx->build.quad_pack.ptr;
+    s.tri_shade = ctx->build.tri_shade.ptr;
     s.sphere_ids = (const uint32_t *)ctx->build.sphere_ids.ptr; s.quad_ids = (const uint32_t *)ctx->build.quad_ids.ptr;
     s.spheres = (const crt_sphere *)ctx->spheres.ptr; s.quads = (const crt_quad *)ctx->quads.ptr; s.tris = (const crt_tri *)ctx->tris.ptr;
     s.materials = (const crt_material *)ctx->materials.ptr;

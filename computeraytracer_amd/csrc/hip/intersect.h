@@ -20,6 +20,7 @@ struct DeviceScene {
     const float4 *tri_pack;     // sorted slot s: {v0.xyz, e10.x} {e10.y, e10.z, e20.x, e20.y} {e20.z, id bits, -, -}
     const float4 *sphere_pack;  // sorted slot s: {center.xyz, radius}
     const float4 *quad_pack;    // sorted slot s: {normal.xyz, d} {corner.xyz, u.x} {u.y, u.z, v.x, v.y} {v.z, w.xyz}
+    const float4 *tri_shade;    // input index i: {v0.xyz, e10.x} {e10.yz, e20.xy} {e20.z, materialIndex, u0, u1} {u2, v0, v1, v2} (64 B, one line)
     const uint32_t *sphere_ids; // sorted slot -> input index
     const uint32_t *quad_ids;
     const crt_sphere *spheres;  // as uploaded (input order): shading data
@@ -283,12 +284,11 @@ CRT_DEV void resolve_hit(const DeviceScene &sc, V3 o, V3 d, float t, uint32_t id
     rec.u = 0.0f; rec.v = 0.0f;
     rec.position = o + t * d;
     if (kind == CRT_ID_KIND_TRI) {                       // compute.comp:303-307
-        const float4 *p = (const float4 *)(sc.tris + idx);
-        float4 a = p[0], b = p[1], c = p[2];
-        V3 v0 = mk3(a.x, a.y, a.z);
-        V3 e10 = mk3(b.x, b.y, b.z) - v0, e20 = mk3(c.x, c.y, c.z) - v0;
+        const float4 *p = sc.tri_shade + 4 * (size_t)idx;
+        const float4 a = p[0], b = p[1], c = p[2];
+        const V3 e10 = mk3(a.w, b.x, b.y), e20 = mk3(b.z, b.w, c.x);      // v1 - v0, v2 - v0 (bvh_build.hip: write_tri_shade)
         set_face_normal(d, cross3(e20, e10), rec);       // not normalised (sic)
-        rec.materialIndex = sc.tris[idx].materialIndex;
+        rec.materialIndex = f2u(c.y);
     } else if (kind == CRT_ID_KIND_SPHERE) {             // compute.comp:241-245
         float4 cr = *(const float4 *)(sc.spheres + idx);
         V3 outward = (rec.position - mk3(cr.x, cr.y, cr.z)) / cr.w;
@@ -306,16 +306,15 @@ CRT_DEV void resolve_hit(const DeviceScene &sc, V3 o, V3 d, float t, uint32_t id
 CRT_DEV void resolve_uv(const DeviceScene &sc, V3 o, V3 d, uint32_t id, HitRecord &rec) {
     uint32_t kind = id >> 30, idx = id & 0x3FFFFFFFu;
     if (kind == CRT_ID_KIND_TRI) {                       // compute.comp:309-314
-        const float4 *p = (const float4 *)(sc.tris + idx);
-        float4 a = p[0], b = p[1], c = p[2], tu = p[3], tv = p[4];
-        V3 v0 = mk3(a.x, a.y, a.z);
-        V3 e10 = mk3(b.x, b.y, b.z) - v0, e20 = mk3(c.x, c.y, c.z) - v0;
+        const float4 *p = sc.tri_shade + 4 * (size_t)idx;
+        const float4 a = p[0], b = p[1], c = p[2], e = p[3];
+        const V3 v0 = mk3(a.x, a.y, a.z), e10 = mk3(a.w, b.x, b.y), e20 = mk3(b.z, b.w, c.x);
         float tt, beta, gamma, invDet;
         tri_t(o, d, v0, e10, e20, tt, beta, gamma, invDet);
         beta = beta * invDet; gamma = gamma * invDet;
         float alpha = 1.0f - beta - gamma;
-        rec.u = (alpha * tu.x + beta * tu.y) + gamma * tu.z;
-        rec.v = (alpha * tv.x + beta * tv.y) + gamma * tv.z;
+        rec.u = (alpha * c.z + beta * c.w) + gamma * e.x;
+        rec.v = (alpha * e.y + beta * e.z) + gamma * e.w;
     } else if (kind == CRT_ID_KIND_SPHERE) {             // compute.comp:247-250
         float4 cr = *(const float4 *)(sc.spheres + idx);
         V3 outward = (rec.position - mk3(cr.x, cr.y, cr.z)) / cr.w;

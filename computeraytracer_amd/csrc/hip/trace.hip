@@ -37,6 +37,7 @@ static DeviceScene to_device_scene(const DeviceSceneHost &h) {
     d.nodes = (const float4 *)h.nodes; d.n_pairs = h.n_pairs;
     d.wide = (const float4 *)h.wide; d.n_wide = h.n_wide;
     d.tri_pack = (const float4 *)h.tri_pack; d.sphere_pack = (const float4 *)h.sphere_pack; d.quad_pack = (const float4 *)h.quad_pack;
+    d.tri_shade = (const float4 *)h.tri_shade;
     d.sphere_ids = h.sphere_ids; d.quad_ids = h.quad_ids;
     d.spheres = h.spheres; d.quads = h.quads; d.tris = h.tris; d.materials = h.materials;
     d.tex0 = h.tex0; d.tex0_w = h.tex0_w; d.tex0_h = h.tex0_h; d.n_textures = h.n_textures;
