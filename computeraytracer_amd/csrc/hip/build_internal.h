@@ -89,7 +89,7 @@ struct WavefrontState {
     uint32_t capacity = 0;           // paths the queues can hold
     DeviceBuffer ray_o[2], ray_d[2], thr[2], hit, counters, pass, query_rays;
     bool time_kernels = false;
-    std::vector<hipEvent_t> ev;      // start/stop pairs around extend launches
+    std::vector<hipEvent_t> ev;      // per bounce: before k_wf_extend, between it and k_wf_shade, after k_wf_shade
     size_t ev_used = 0;
 };
 

@@ -579,8 +579,8 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     else hipLaunchKernelGGL((k_wf_generate<0>), gen_grid, block, 0, stream, sc, f, q, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
     for (uint32_t b = 0; b < f.max_bounces; b++) {
         const unsigned long long dead_b = b == 0 ? dead : 0ull;
-        if (wf.time_kernels) {
-            if (wf.ev_used + 2 > wf.ev.size()) { hipEvent_t a, c; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&c)); wf.ev.push_back(a); wf.ev.push_back(c); }
+        if (wf.time_kernels) {      // three events per bounce: before extend, between extend and shade, after shade
+            while (wf.ev_used + 3 > wf.ev.size()) { hipEvent_t a; HIP_TRY(hipEventCreate(&a)); wf.ev.push_back(a); }
             HIP_TRY(hipEventRecord(wf.ev[wf.ev_used], stream));
         }
         q.lds_depth = fs.small_stack ? 1u : (sc.wide ? (uint32_t)kWideLds : (uint32_t)kLdsStack);
@@ -594,9 +594,10 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
             if (fs.instrumented) hipLaunchKernelGGL((k_wf_extend<true, false, true>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
             else hipLaunchKernelGGL((k_wf_extend<false, false, true>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
         }
-        if (wf.time_kernels) { HIP_TRY(hipEventRecord(wf.ev[wf.ev_used + 1], stream)); wf.ev_used += 2; }
+        if (wf.time_kernels) HIP_TRY(hipEventRecord(wf.ev[wf.ev_used + 1], stream));
         if (pcg) hipLaunchKernelGGL((k_wf_shade<1>), sgrid, block, 0, stream, sc, f, q, b, (float4 *)wf.pass.ptr, accum_pixels, hit_ids);
         else hipLaunchKernelGGL((k_wf_shade<0>), sgrid, block, 0, stream, sc, f, q, b, (float4 *)wf.pass.ptr, accum_pixels, hit_ids);
+        if (wf.time_kernels) { HIP_TRY(hipEventRecord(wf.ev[wf.ev_used + 2], stream)); wf.ev_used += 3; }
     }
     hipLaunchKernelGGL(k_wf_accumulate, acc_grid, block, 0, stream, f, acc, (const float4 *)wf.pass.ptr, accum_pixels);
     HIP_TRY(hipGetLastError());

@@ -176,8 +176,9 @@ int crt_set_instrumented(crt_context *ctx, int on);
  * {loop iterations, inner-phase iterations, lanes stepping in them, leaf-phase iterations, lanes testing in them,
  * iterations that refilled lanes}, summed over waves.  Build-only diagnostic (no counterpart in the reference). */
 int crt_loop_counters_read(crt_context *ctx, uint64_t *out, uint32_t n_words);
-/* Brackets every k_wf_extend launch (the dominant kernel) with HIP events on the context's stream so that
- * crt_stats.last_extend_ms reports its device time separately (bench.py's roofline figure). */
+/* Brackets every k_wf_extend launch (the dominant kernel) and every k_wf_shade launch with HIP events on the context's
+ * stream so that crt_stats.last_extend_ms / last_shade_ms report their device time separately (bench.py's roofline
+ * figures).  While it is on, crt_dispatch / crt_render wait for the previous call's events before reusing them. */
 int crt_set_kernel_timing(crt_context *ctx, int on);
 
 /* Read back the build's BVH for cross-checks: nodes (pair layout, see

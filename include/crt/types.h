@@ -211,6 +211,8 @@ typedef struct crt_stats {
     double   last_extend_ms;  /* summed device time of the k_wf_extend launches of the last crt_dispatch/crt_render
                                  (only with crt_set_kernel_timing on and the wavefront tracer; else 0) */
     uint64_t last_extend_launches;
+    double   last_shade_ms;   /* the same for the k_wf_shade launches */
+    uint64_t last_shade_launches;
 } crt_stats;
 
 #ifdef __cplusplus
