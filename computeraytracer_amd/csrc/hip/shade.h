@@ -18,10 +18,8 @@ CRT_DEV void camera_get_ray(const crt_camera_data &cam, float u, float v, Rng<M>
 }
 
 // RGBA8 UNORM, bilinear, REPEAT, texel centres at +0.5 (vk_initializers.cpp:252-261); plain float weights.
-CRT_DEV V3 texel(const uint8_t *tex, uint32_t w, int x, int y) {
-    uint32_t p = *(const uint32_t *)(tex + 4 * ((size_t)y * w + (size_t)x));
-    return mk3((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f);
-}
+CRT_DEV V3 unpack_rgb(uint32_t p) { return mk3((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f); }
+CRT_DEV V3 texel(const uint8_t *tex, uint32_t w, int x, int y) { return unpack_rgb(*(const uint32_t *)(tex + 4 * ((size_t)y * w + (size_t)x))); }
 CRT_DEV int wrapi(float f, int n) { int i = (int)f % n; return i < 0 ? i + n : i; }
 CRT_DEV V3 sample_texture(const uint8_t *tex, uint32_t w, uint32_t h, float u, float v) {
     float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
@@ -29,7 +27,15 @@ CRT_DEV V3 sample_texture(const uint8_t *tex, uint32_t w, uint32_t h, float u, f
     float fx = x - x0f, fy = y - y0f;
     int x0 = wrapi(x0f, (int)w), y0 = wrapi(y0f, (int)h);
     int x1 = x0 + 1 == (int)w ? 0 : x0 + 1, y1 = y0 + 1 == (int)h ? 0 : y0 + 1;
-    V3 t00 = texel(tex, w, x0, y0), t10 = texel(tex, w, x1, y0), t01 = texel(tex, w, x0, y1), t11 = texel(tex, w, x1, y1);
+    V3 t00, t10, t01, t11;
+    if (x1 == x0 + 1) {
+        // the two texels of a row sit side by side (no wrap): one 8-byte load per row instead of two 4-byte ones; the
+        // address path of k_wf_shade is its busiest unit (TA_BUSY 0.75) and these are fully divergent accesses
+        const uint2 top2 = *(const uint2 *)(tex + 4 * ((size_t)y0 * w + (size_t)x0)), bot2 = *(const uint2 *)(tex + 4 * ((size_t)y1 * w + (size_t)x0));
+        t00 = unpack_rgb(top2.x); t10 = unpack_rgb(top2.y); t01 = unpack_rgb(bot2.x); t11 = unpack_rgb(bot2.y);
+    } else {
+        t00 = texel(tex, w, x0, y0); t10 = texel(tex, w, x1, y0); t01 = texel(tex, w, x0, y1); t11 = texel(tex, w, x1, y1);
+    }
     V3 top = t00 * (1.0f - fx) + t10 * fx;
     V3 bot = t01 * (1.0f - fx) + t11 * fx;
     return top * (1.0f - fy) + bot * fy;
