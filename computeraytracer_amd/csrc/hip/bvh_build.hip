@@ -124,8 +124,10 @@ __device__ __forceinline__ uint64_t expand_bits21(uint64_t v) {
 
 // Morton code of the centroid, `bits` per axis (cells finer than the
 // primitives' spacing keep equal codes, which the hierarchy can only split by index, rare).
-__global__ void k_morton(uint32_t n, uint32_t bits, const float4 *plo, const float4 *phi, const uint32_t *scene_bounds,
-                         uint64_t *keys, uint32_t *vals) {
+// With idx_bits != 0 the key carries the primitive's index below the code (code << idx_bits | g): the sort then moves
+// keys only, over the code's bits, and k_hierarchy recovers the order from the low bits.
+__global__ void k_morton(uint32_t n, uint32_t bits, uint32_t idx_bits, const float4 *plo, const float4 *phi,
+                         const uint32_t *scene_bounds, uint64_t *keys, uint32_t *vals) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
     float4 lo = plo[g], hi = phi[g];
@@ -141,7 +143,9 @@ __global__ void k_morton(uint32_t n, uint32_t bits, const float4 *plo, const flo
         float f = ext > 0.0f ? (c[a] - mn) / ext : 0.0f;
         q[a] = (uint64_t)fminf(fmaxf(f * cells, 0.0f), cells - 1.0f);
     }
-    keys[g] = (expand_bits21(q[0]) << 2) | (expand_bits21(q[1]) << 1) | expand_bits21(q[2]);
+    const uint64_t code = (expand_bits21(q[0]) << 2) | (expand_bits21(q[1]) << 1) | expand_bits21(q[2]);
+    if (idx_bits) { keys[g] = code << idx_bits | g; return; }
+    keys[g] = code;
     vals[g] = g;
 }
 
@@ -155,7 +159,7 @@ __global__ void k_kind_flags(uint32_t n, const uint32_t *vals, uint32_t ns, uint
 
 // Traversal records in sorted order.  leaf_link[s] = slot inside the kind's array, leaf_count[s] = kind << 28 | 1.
 __global__ void k_pack(BuildInput in, uint32_t n, const uint32_t *vals, const uint32_t *rank_sphere, const uint32_t *rank_quad,
-                       float4 *tri_pack, float4 *sphere_pack, float4 *quad_pack, uint32_t *sphere_ids, uint32_t *quad_ids,
+                       const float4 *tri_shade, float4 *tri_pack, float4 *sphere_pack, float4 *quad_pack, uint32_t *sphere_ids, uint32_t *quad_ids,
                        uint32_t *tri_ids, uint32_t *leaf_link, uint32_t *leaf_count) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
@@ -180,15 +184,14 @@ __global__ void k_pack(BuildInput in, uint32_t n, const uint32_t *vals, const ui
     } else {
         uint32_t i = g - in.n_spheres - in.n_quads;
         uint32_t rt = s - rs - rq;
-        const float4 *tp = (const float4 *)(in.tris + i);
-        const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-        // e10 = v1 - v0, e20 = v2 - v0: the same two IEEE subtractions hit_tri performs (compute.comp:281-282)
-        float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
-        float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
+        // v0, e10 = v1 - v0, e20 = v2 - v0 (the two IEEE subtractions of hit_tri, compute.comp:281-282) are the head of
+        // the triangle's 64-byte shading record, written by k_prim_bounds: half a cache line instead of a 96-byte upload record
+        const float4 *tp = tri_shade + 4 * (size_t)i;
+        const float4 a = tp[0], b = tp[1], c = tp[2];
         float4 *o = tri_pack + 3 * (size_t)rt;
-        o[0] = make_float4(v0.x, v0.y, v0.z, e1x);
-        o[1] = make_float4(e1y, e1z, e2x, e2y);
-        o[2] = make_float4(e2z, __uint_as_float(CRT_MAKE_ID(CRT_ID_KIND_TRI, i)), 0.0f, 0.0f);
+        o[0] = a;
+        o[1] = b;
+        o[2] = make_float4(c.x, __uint_as_float(CRT_MAKE_ID(CRT_ID_KIND_TRI, i)), 0.0f, 0.0f);
         tri_ids[rt] = i;
         leaf_link[s] = rt; leaf_count[s] = (CRT_ID_KIND_TRI << 28) | 1u;
     }
@@ -203,10 +206,15 @@ __device__ __forceinline__ int delta(const uint64_t *keys, int n, int i, int j) 
 }
 
 // Node numbering: inner i in [0, n-2], leaf j -> (n - 1) + j.  parent[] is indexed by that numbering.
+// unpack_vals (packed keys only): vals[i] = the index in the key's low bits, written on the way.
 __global__ void k_hierarchy(int n, const uint64_t *keys, uint32_t *child_l, uint32_t *child_r, uint32_t *parent,
-                            uint32_t *range_lo, uint32_t *range_hi) {
+                            uint32_t *range_lo, uint32_t *range_hi, uint32_t *unpack_vals, uint32_t idx_mask) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
+    if (unpack_vals) {
+        unpack_vals[i] = (uint32_t)keys[i] & idx_mask;
+        if (i == n - 2) unpack_vals[n - 1] = (uint32_t)keys[n - 1] & idx_mask;
+    }
     int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
     int dmin = delta(keys, n, i, i - d);
     int lmax = 2;
@@ -493,16 +501,27 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     // reference scenes' ground sphere of radius 2000) must not leave a whole mesh in a single cell: 21 bits per axis
     // whenever the sort's cost does not depend on the key width (rocPRIM merge-sorts below about a million keys);
     // above that, four more than half of log2(n) (surfaces are 2-D sets), which saves a radix pass at 10 M.
-    uint32_t bits = 21;
+    uint32_t bits = 21, half_log = 21;
     if (n > (1u << 20)) {
-        bits = 1;
-        while ((1ull << (2 * (bits - 1))) < (uint64_t)n && bits < 21) bits++;
-        bits = bits + 4 > 21 ? 21 : bits + 4;
+        half_log = 1;
+        while ((1ull << (2 * (half_log - 1))) < (uint64_t)n && half_log < 21) half_log++;
+        bits = half_log + 4 > 21 ? 21 : half_log + 4;
+    }
+    // Above the merge-sort range every radix pass is a trip of keys and values through HBM.  When the code and the index
+    // fit one 64-bit word together (code << idx_bits | index) with no fewer bits per axis than half of log2(n),
+    // the sort moves keys only and over the code's bits only: 5 passes of 8 bytes instead of 7 of 12 at 10 M.
+    uint32_t idx_bits = 0;
+    if (n > (1u << 20) && !getenv("CRT_BVH_SORT_PAIRS")) {
+        uint32_t ib = 1;
+        while ((1ull << ib) < (uint64_t)n) ib++;
+        const uint32_t fit = std::min(21u, (64u - ib) / 3u);
+        if (fit >= half_log) { idx_bits = ib; bits = std::min(bits, fit); }
     }
     const unsigned key_bits = 3 * bits;
     rocprim::double_buffer<uint64_t> dkeys((uint64_t *)st.keys.ptr, (uint64_t *)st.keys_alt.ptr);
     rocprim::double_buffer<uint32_t> dvals((uint32_t *)st.vals.ptr, (uint32_t *)st.vals_alt.ptr);
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, dkeys, dvals, n, 0, key_bits, stream));
+    if (idx_bits) HIP_TRY(rocprim::radix_sort_keys(nullptr, sort_bytes, dkeys, n, idx_bits, idx_bits + key_bits, stream));
+    else HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, dkeys, dvals, n, 0, key_bits, stream));
     HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t *)st.flag_a.ptr, (uint32_t *)st.rank_a.ptr, 0u, n,
                                     rocprim::plus<uint32_t>(), stream));
     if (!ensure(st.temp, std::max(sort_bytes, scan_bytes), err)) return false;
@@ -510,11 +529,12 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, (uint32_t *)st.scene_bounds.ptr);
     hipLaunchKernelGGL(k_prim_bounds, dim3(std::min(blocks, 4096u)), dim3(256), 0, stream, in, n, (float4 *)st.plo.ptr, (float4 *)st.phi.ptr,
                        (float4 *)st.tri_shade.ptr, (uint32_t *)st.scene_bounds.ptr);
-    hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, bits, (const float4 *)st.plo.ptr, (const float4 *)st.phi.ptr,
-                       (const uint32_t *)st.scene_bounds.ptr, (uint64_t *)st.keys.ptr, (uint32_t *)st.vals.ptr);
+    hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, bits, idx_bits, (const float4 *)st.plo.ptr,
+                       (const float4 *)st.phi.ptr, (const uint32_t *)st.scene_bounds.ptr, (uint64_t *)st.keys.ptr, (uint32_t *)st.vals.ptr);
     HIP_TRY(hipGetLastError());
     size_t tb = st.temp.bytes;
-    HIP_TRY(rocprim::radix_sort_pairs(st.temp.ptr, tb, dkeys, dvals, n, 0, key_bits, stream));
+    if (idx_bits) HIP_TRY(rocprim::radix_sort_keys(st.temp.ptr, tb, dkeys, n, idx_bits, idx_bits + key_bits, stream));
+    else HIP_TRY(rocprim::radix_sort_pairs(st.temp.ptr, tb, dkeys, dvals, n, 0, key_bits, stream));
     const uint64_t *keys = dkeys.current(); const uint32_t *vals = dvals.current();
 
     // SAH refinement: the Karras hierarchy only clusters; bvh_sah.hip rebuilds the topology and reorders the primitives
@@ -524,7 +544,7 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
         if (!ensure(st.range_lo, (size_t)n * 4, err) || !ensure(st.range_hi, (size_t)n * 4, err)) return false;
         hipLaunchKernelGGL(k_hierarchy, dim3((n - 1 + 255) / 256), dim3(256), 0, stream, (int)n, keys, (uint32_t *)st.child_l.ptr,
                            (uint32_t *)st.child_r.ptr, (uint32_t *)st.parent.ptr, (uint32_t *)st.range_lo.ptr,
-                           (uint32_t *)st.range_hi.ptr);
+                           (uint32_t *)st.range_hi.ptr, idx_bits ? (uint32_t *)vals : nullptr, (uint32_t)((1ull << idx_bits) - 1));
         HIP_TRY(hipGetLastError());
     }
     if (sah) {
@@ -547,7 +567,7 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
                                         rocprim::plus<uint32_t>(), stream));
     }
     hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, stream, in, n, order, mixed ? (const uint32_t *)st.rank_a.ptr : nullptr,
-                       mixed ? (const uint32_t *)st.rank_b.ptr : nullptr, (float4 *)st.tri_pack.ptr, (float4 *)st.sphere_pack.ptr,
+                       mixed ? (const uint32_t *)st.rank_b.ptr : nullptr, (const float4 *)st.tri_shade.ptr, (float4 *)st.tri_pack.ptr, (float4 *)st.sphere_pack.ptr,
                        (float4 *)st.quad_pack.ptr, (uint32_t *)st.sphere_ids.ptr, (uint32_t *)st.quad_ids.ptr,
                        (uint32_t *)st.tri_ids.ptr, (uint32_t *)st.leaf_link.ptr, (uint32_t *)st.leaf_count.ptr);
     HIP_TRY(hipGetLastError());
