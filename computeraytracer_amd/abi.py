@@ -20,6 +20,8 @@ TRACER_MEGAKERNEL, TRACER_WAVEFRONT = 0, 1
 FLAG_FULL_IMAGE = 1
 FLAG_DEBUG_SMALL_STACK = 2
 BVH_LBVH, BVH_SAH_REFINE, BVH_LEAF_COLLAPSE, BVH_WIDE = 0, 1, 2, 4
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT = 1, 2, 4, 8     # crt_material.type (rt_material.h:9-14)
+EXT_TEXTURE_INDEX, EXT_ALPHA_TEST = 1, 2     # crt_extensions_set (build extensions, off by default)
 
 # numpy views of the POD layouts in include/crt/types.h
 sphere_dtype = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("pad0", "<f4", 3), ("materialIndex", "<u4")])
@@ -88,6 +90,7 @@ def _load():
         "crt_last_error": (C.c_char_p, [vp]),
         "crt_configure": (i32, [vp, P(Config)]),
         "crt_scene_upload": (i32, [vp, P(SceneDesc)]),
+        "crt_extensions_set": (i32, [vp, u32]),
         "crt_bvh_build": (i32, [vp, u32, P(f32)]),
         "crt_tris_update": (i32, [vp, vp, u32, u32]),
         "crt_tris_animate": (i32, [vp, f32, f32]),
@@ -318,6 +321,9 @@ class Context:
         self._scene = scene
         d = scene.desc()
         self._check(lib.crt_scene_upload(self._h, C.byref(d)), "crt_scene_upload")
+
+    def extensions_set(self, ext_flags):
+        self._check(lib.crt_extensions_set(self._h, ext_flags), "crt_extensions_set")
 
     def build(self, flags=BVH_LBVH):
         ms = C.c_float()

@@ -26,9 +26,11 @@ struct crt_context {
     crt_config cfg{};
     bool configured = false, have_scene = false, have_bvh = false;
     // scene (reference layouts, input order)
-    DeviceBuffer spheres, quads, tris, tris_rest, materials, tex0, dbg_boxes;
+    DeviceBuffer spheres, quads, tris, tris_rest, materials, tex0, tex_table, dbg_boxes;      // tex0: every texture, textures[0] first
     uint32_t n_dbg_boxes = 0;
     uint32_t n_spheres = 0, n_quads = 0, n_tris = 0, n_materials = 0, n_textures = 0, tex0_w = 0, tex0_h = 0;
+    uint32_t ext = 0;               // CRT_EXT_* (crt_extensions_set)
+    bool tex_index_ok = true;       // every material's textureIndex is CRT_BAD_INDEX or < n_textures
     bool animated = false;
     BuildState build;
     // image
@@ -87,6 +89,7 @@ DeviceSceneHost scene_view(const crt_context *ctx) {
     s.spheres = (const crt_sphere *)ctx->spheres.ptr; s.quads = (const crt_quad *)ctx->quads.ptr; s.tris = (const crt_tri *)ctx->tris.ptr;
     s.materials = (const crt_material *)ctx->materials.ptr;
     s.tex0 = (const uint8_t *)ctx->tex0.ptr; s.tex0_w = ctx->tex0_w; s.tex0_h = ctx->tex0_h; s.n_textures = ctx->n_textures;
+    s.tex_table = (const uint4 *)ctx->tex_table.ptr; s.ext = ctx->ext;
     s.dbg_boxes = ctx->n_dbg_boxes ? ctx->dbg_boxes.ptr : nullptr; s.n_dbg_boxes = ctx->n_dbg_boxes;
     return s;
 }
@@ -211,7 +214,7 @@ void crt_destroy(crt_context *ctx) {
     if (!ctx) return;
     if (hipSetDevice(ctx->device) == hipSuccess) {
         hipError_t e = hipStreamSynchronize(ctx->stream); (void)e;
-        DeviceBuffer *all[] = {&ctx->spheres, &ctx->quads, &ctx->tris, &ctx->tris_rest, &ctx->materials, &ctx->tex0, &ctx->dbg_boxes, &ctx->accum, &ctx->hit_ids, &ctx->stats};
+        DeviceBuffer *all[] = {&ctx->spheres, &ctx->quads, &ctx->tris, &ctx->tris_rest, &ctx->materials, &ctx->tex0, &ctx->tex_table, &ctx->dbg_boxes, &ctx->accum, &ctx->hit_ids, &ctx->stats};
         for (DeviceBuffer *b : all) release(*b);
         free_build_state(ctx->build);
         free_wavefront(ctx->wf);
@@ -276,6 +279,11 @@ int crt_scene_upload(crt_context *ctx, const crt_scene_desc *s) {
     for (uint32_t i = 0; i < s->n_tris; i++) if (s->tris[i].materialIndex >= s->n_materials) return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload: triangle material index out of range");
     for (uint32_t i = 0; i < s->n_textures; i++)
         if (!s->textures[i].rgba8 || s->textures[i].width == 0 || s->textures[i].height == 0) return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload: empty texture");
+    bool tex_index_ok = true;
+    for (uint32_t i = 0; i < s->n_materials; i++)
+        if (s->materials[i].textureIndex != CRT_BAD_INDEX && s->materials[i].textureIndex >= s->n_textures) tex_index_ok = false;
+    if ((ctx->ext & CRT_EXT_TEXTURE_INDEX) && !tex_index_ok)
+        return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload: a material's textureIndex is past the texture array (CRT_EXT_TEXTURE_INDEX is set)");
     CTX_HIP(hipStreamSynchronize(ctx->stream));
     ctx->have_scene = false; ctx->have_bvh = false; ctx->animated = false; ctx->n_dbg_boxes = 0;
     if ((rc = upload(ctx, ctx->spheres, s->spheres, (size_t)s->n_spheres * sizeof(crt_sphere)))) return rc;
@@ -284,13 +292,36 @@ int crt_scene_upload(crt_context *ctx, const crt_scene_desc *s) {
     if ((rc = upload(ctx, ctx->materials, s->materials, (size_t)s->n_materials * sizeof(crt_material)))) return rc;
     ctx->n_spheres = s->n_spheres; ctx->n_quads = s->n_quads; ctx->n_tris = s->n_tris; ctx->n_materials = s->n_materials;
     ctx->n_textures = s->n_textures; ctx->tex0_w = ctx->tex0_h = 0;
+    ctx->tex_index_ok = tex_index_ok;
     if (s->n_textures) {
-        // the shader samples textures[0] only (compute.comp:386-387), so that is the one resident texture
-        const crt_texture &t = s->textures[0];
-        if ((rc = upload(ctx, ctx->tex0, t.rgba8, (size_t)t.width * t.height * 4))) return rc;
-        ctx->tex0_w = t.width; ctx->tex0_h = t.height;
+        // The shader samples textures[0] only (compute.comp:386-387); the others are resident behind it, in one allocation,
+        // for CRT_EXT_TEXTURE_INDEX.  tex_table[i] = {first texel, width, height, 0}.
+        std::vector<uint32_t> table(4 * (size_t)s->n_textures);
+        size_t texels = 0;
+        for (uint32_t i = 0; i < s->n_textures; i++) {
+            const crt_texture &t = s->textures[i];
+            if (texels > 0xFFFFFFFFull) return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload: more than 2^32 texels of textures");
+            table[4 * i] = (uint32_t)texels; table[4 * i + 1] = t.width; table[4 * i + 2] = t.height; table[4 * i + 3] = 0;
+            texels += (size_t)t.width * t.height;
+        }
+        if ((rc = alloc(ctx, ctx->tex0, texels * 4))) return rc;
+        for (uint32_t i = 0; i < s->n_textures; i++) {
+            const crt_texture &t = s->textures[i];
+            CTX_HIP(hipMemcpy((uint8_t *)ctx->tex0.ptr + 4 * (size_t)table[4 * i], t.rgba8, (size_t)t.width * t.height * 4, hipMemcpyHostToDevice));   // synchronous: the caller's pixels may go away after this call
+        }
+        if ((rc = upload(ctx, ctx->tex_table, table.data(), table.size() * 4))) return rc;
+        ctx->tex0_w = s->textures[0].width; ctx->tex0_h = s->textures[0].height;
     }
     ctx->have_scene = true;
+    return CRT_OK;
+}
+
+int crt_extensions_set(crt_context *ctx, uint32_t ext_flags) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (ext_flags & ~(uint32_t)(CRT_EXT_TEXTURE_INDEX | CRT_EXT_ALPHA_TEST)) return fail(ctx, CRT_ERR_INVALID, "crt_extensions_set: unknown extension bit");
+    if ((ext_flags & CRT_EXT_TEXTURE_INDEX) && ctx->have_scene && !ctx->tex_index_ok)
+        return fail(ctx, CRT_ERR_INVALID, "crt_extensions_set: a material's textureIndex is past the texture array");
+    ctx->ext = ext_flags;
     return CRT_OK;
 }
 

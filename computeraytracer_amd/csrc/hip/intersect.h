@@ -27,9 +27,12 @@ struct DeviceScene {
     const crt_quad *quads;
     const crt_tri *tris;
     const crt_material *materials;
-    const uint8_t *tex0;        // textures[0], RGBA8 rows top-down (the shader only ever samples index 0, compute.comp:387)
+    const uint8_t *tex0;        // textures[0], RGBA8 rows top-down (the shader only ever samples index 0, compute.comp:387);
+                                // the scene's other textures follow it in the same allocation (tex_table)
     uint32_t tex0_w, tex0_h;
     uint32_t n_textures;
+    const uint4 *tex_table;     // texture i: {first texel (offset from tex0 in texels), width, height, -}
+    uint32_t ext;               // CRT_EXT_* build extensions (crt_extensions_set); 0 = the reference's behaviour
     const float4 *dbg_boxes;    // crt_debug_boxes_upload: the reference's BVHNode array (64-byte stride), or null
     uint32_t n_dbg_boxes;
 };
@@ -93,6 +96,49 @@ CRT_DEV bool tri_t(V3 o, V3 d, V3 v0, V3 e10, V3 e20, float &t, float &beta, flo
 
 struct Counts { uint32_t nodes, prims; };
 
+// ---- build extensions (crt_extensions_set; no counterpart in the reference, off by default) ----
+CRT_DEV int wrapi(float f, int n) { int i = (int)f % n; return i < 0 ? i + n : i; }
+
+// The texture a material samples: textures[0] as the shader does (compute.comp:387), or textures[textureIndex] with
+// CRT_EXT_TEXTURE_INDEX (crt_scene_upload / crt_extensions_set refuse an index past the array).
+CRT_DEV const uint8_t *material_texture(const DeviceScene &sc, uint32_t texIndex, uint32_t &w, uint32_t &h) {
+    w = sc.tex0_w; h = sc.tex0_h;
+    if (!(sc.ext & CRT_EXT_TEXTURE_INDEX)) return sc.tex0;
+    const uint4 e = sc.tex_table[texIndex];
+    w = e.y; h = e.z;
+    return sc.tex0 + 4 * (size_t)e.x;
+}
+
+// Alpha channel through the colour fetch's sampler (shade.h sample_texture: bilinear, REPEAT, centres at +0.5).
+CRT_DEV float texture_alpha(const uint8_t *tex, uint32_t w, uint32_t h, float u, float v) {
+    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    float x0f = __builtin_floorf(x), y0f = __builtin_floorf(y);
+    float fx = x - x0f, fy = y - y0f;
+    int x0 = wrapi(x0f, (int)w), y0 = wrapi(y0f, (int)h);
+    int x1 = x0 + 1 == (int)w ? 0 : x0 + 1, y1 = y0 + 1 == (int)h ? 0 : y0 + 1;
+    const float a00 = (float)tex[4 * ((size_t)y0 * w + (size_t)x0) + 3] / 255.0f, a10 = (float)tex[4 * ((size_t)y0 * w + (size_t)x1) + 3] / 255.0f;
+    const float a01 = (float)tex[4 * ((size_t)y1 * w + (size_t)x0) + 3] / 255.0f, a11 = (float)tex[4 * ((size_t)y1 * w + (size_t)x1) + 3] / 255.0f;
+    float top = a00 * (1.0f - fx) + a10 * fx;
+    float bot = a01 * (1.0f - fx) + a11 * fx;
+    return top * (1.0f - fy) + bot * fy;
+}
+
+// CRT_EXT_ALPHA_TEST: a triangle hit counts only where its material's texture is opaque (alpha >= 0.5 at the hit's
+// (u, v), compute.comp:309-314 for the coordinates).  beta, gamma, invDet are tri_t's for this ray and triangle.
+CRT_DEV bool tri_alpha_pass(const DeviceScene &sc, uint32_t id, float beta, float gamma, float invDet) {
+    const float4 *p = sc.tri_shade + 4 * (size_t)(id & 0x3FFFFFFFu);
+    const float4 c = p[2], e = p[3];
+    const uint32_t texIndex = sc.materials[f2u(c.y)].textureIndex;
+    if (texIndex == CRT_BAD_INDEX || sc.n_textures == 0) return true;
+    beta = beta * invDet; gamma = gamma * invDet;
+    const float alpha = 1.0f - beta - gamma;
+    const float u = (alpha * c.z + beta * c.w) + gamma * e.x;
+    const float v = (alpha * e.y + beta * e.z) + gamma * e.w;
+    uint32_t w, h;
+    const uint8_t *tex = material_texture(sc, texIndex, w, h);
+    return !(texture_alpha(tex, w, h, u, v) < 0.5f);
+}
+
 // Slab test for culling only (R5).  fma form: t = b * (1/d) - o * (1/d).  Boxes are padded at build
 // time and the far bound carries a relative pad, so rounding here never culls a primitive that an
 // exhaustive test would accept.
@@ -108,7 +154,9 @@ CRT_DEV bool slab(float4 lo, float4 hi, V3 idir, V3 noid, float tfar, float &tn)
     return tn <= tf;
 }
 
-template <bool COUNT>
+// ALPHA: compiled only into the kernels that run when CRT_EXT_ALPHA_TEST is set (as a run-time branch it cost the
+// headline k_wf_extend 18 spilled VGPRs).
+template <bool COUNT, bool ALPHA>
 CRT_DEV void test_leaf(const DeviceScene &sc, V3 o, V3 d, uint32_t first, uint32_t count_kind, float &best_t, uint32_t &best_id, Counts &cnt) {
     uint32_t kind = count_kind >> 28, n = count_kind & 0x0FFFFFFFu;
     if (COUNT) cnt.prims += n;
@@ -119,7 +167,7 @@ CRT_DEV void test_leaf(const DeviceScene &sc, V3 o, V3 d, uint32_t first, uint32
             float t, beta, gamma, invDet;
             if (tri_t(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, beta, gamma, invDet)) {
                 uint32_t id = f2u(c.y);
-                if (accept_hit(t, id, best_t, best_id)) { best_t = t; best_id = id; }
+                if (accept_hit(t, id, best_t, best_id) && (!ALPHA || tri_alpha_pass(sc, id, beta, gamma, invDet))) { best_t = t; best_id = id; }
             }
         }
     } else if (kind == CRT_ID_KIND_SPHERE) {
@@ -142,7 +190,7 @@ CRT_DEV void test_leaf(const DeviceScene &sc, V3 o, V3 d, uint32_t first, uint32
 }
 
 // R6: closest hit.  `stack` points at this lane's column of the block's LDS stack (stride = blockDim).
-template <bool COUNT>
+template <bool COUNT, bool ALPHA = false>
 CRT_DEV void closest_hit(const DeviceScene &sc, V3 o, V3 d, uint32_t *stack, uint32_t stack_stride,
                          float &best_t, uint32_t &best_id, Counts &cnt) {
     best_t = kInf; best_id = kIdMiss;
@@ -164,8 +212,8 @@ CRT_DEV void closest_hit(const DeviceScene &sc, V3 o, V3 d, uint32_t *stack, uin
         bool h0 = slab(lo0, hi0, idir, noid, tfar, tn0);
         bool h1 = slab(lo1, hi1, idir, noid, tfar, tn1);
         uint32_t c0 = f2u(hi0.w), c1 = f2u(hi1.w);
-        if (h0 && c0 != 0) { test_leaf<COUNT>(sc, o, d, f2u(lo0.w), c0, best_t, best_id, cnt); h0 = false; }
-        if (h1 && c1 != 0) { test_leaf<COUNT>(sc, o, d, f2u(lo1.w), c1, best_t, best_id, cnt); h1 = false; }
+        if (h0 && c0 != 0) { test_leaf<COUNT, ALPHA>(sc, o, d, f2u(lo0.w), c0, best_t, best_id, cnt); h0 = false; }
+        if (h1 && c1 != 0) { test_leaf<COUNT, ALPHA>(sc, o, d, f2u(lo1.w), c1, best_t, best_id, cnt); h1 = false; }
         tfar = best_t * 1.000004f;       // relative pad (2^-18) on the far bound
         uint32_t l0 = f2u(lo0.w), l1 = f2u(lo1.w);
         if (h0 && h1) {
@@ -245,11 +293,11 @@ CRT_DEV bool trav_inner(const DeviceScene &sc, Traversal &tr, uint32_t *stack, u
 }
 
 // Leaf phase: test the primitives of the leaf entry in tr.cur, then pop.
-template <bool COUNT>
+template <bool COUNT, bool ALPHA = false>
 CRT_DEV bool trav_leaf(const DeviceScene &sc, Traversal &tr, const uint32_t *stack, uint32_t stack_stride, const uint32_t *spill, int lds_depth, Counts &cnt) {
     const uint32_t e = tr.cur;
     const uint32_t kind = (e >> 29) & 3u, n = ((e >> 26) & 7u) + 1u, first = e & (kMaxLeafLink - 1u);
-    test_leaf<COUNT>(sc, tr.o, tr.d, first, (kind << 28) | n, tr.best_t, tr.best_id, cnt);
+    test_leaf<COUNT, ALPHA>(sc, tr.o, tr.d, first, (kind << 28) | n, tr.best_t, tr.best_id, cnt);
     tr.tfar = tr.best_t * 1.000004f;       // relative pad (2^-18) on the far bound
     return trav_pop(tr, stack, stack_stride, spill, lds_depth);
 }

@@ -20,7 +20,6 @@ CRT_DEV void camera_get_ray(const crt_camera_data &cam, float u, float v, Rng<M>
 // RGBA8 UNORM, bilinear, REPEAT, texel centres at +0.5 (vk_initializers.cpp:252-261); plain float weights.
 CRT_DEV V3 unpack_rgb(uint32_t p) { return mk3((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f); }
 CRT_DEV V3 texel(const uint8_t *tex, uint32_t w, int x, int y) { return unpack_rgb(*(const uint32_t *)(tex + 4 * ((size_t)y * w + (size_t)x))); }
-CRT_DEV int wrapi(float f, int n) { int i = (int)f % n; return i < 0 ? i + n : i; }
 CRT_DEV V3 sample_texture(const uint8_t *tex, uint32_t w, uint32_t h, float u, float v) {
     float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
     float x0f = __builtin_floorf(x), y0f = __builtin_floorf(y);
@@ -83,7 +82,9 @@ CRT_DEV bool shade_hit(const DeviceScene &sc, V3 &o, V3 &d, float t, uint32_t id
         V3 dir = rec.normal + random_in_unit_sphere(rng);
         if (texIndex != CRT_BAD_INDEX && sc.n_textures > 0) {
             resolve_uv(sc, o, d, id, rec);
-            attenuation = sample_texture(sc.tex0, sc.tex0_w, sc.tex0_h, rec.u, rec.v);   // always textures[0] (sic, :387)
+            uint32_t tw, th;
+            const uint8_t *tex = material_texture(sc, texIndex, tw, th);      // always textures[0] (sic, :387) unless CRT_EXT_TEXTURE_INDEX
+            attenuation = sample_texture(tex, tw, th, rec.u, rec.v);
         }
         o = rec.position; d = normalize3(dir);
     } else if (type == CRT_MAT_METAL) {

@@ -41,6 +41,7 @@ static DeviceScene to_device_scene(const DeviceSceneHost &h) {
     d.sphere_ids = h.sphere_ids; d.quad_ids = h.quad_ids;
     d.spheres = h.spheres; d.quads = h.quads; d.tris = h.tris; d.materials = h.materials;
     d.tex0 = h.tex0; d.tex0_w = h.tex0_w; d.tex0_h = h.tex0_h; d.n_textures = h.n_textures;
+    d.tex_table = h.tex_table; d.ext = h.ext;
     d.dbg_boxes = (const float4 *)h.dbg_boxes; d.n_dbg_boxes = h.n_dbg_boxes;
     return d;
 }
@@ -81,7 +82,7 @@ __device__ __forceinline__ bool tile_pixel(const Frame &f, uint32_t tile, uint32
     return x < f.grid_w && y < f.grid_h;
 }
 
-template <int RNGM, bool COUNT>
+template <int RNGM, bool COUNT, bool ALPHA = false>
 __global__ __launch_bounds__(256) void k_megakernel(DeviceScene sc, Frame f, float4 *accum, uint32_t *hit_ids, DeviceStats *stats) {
     __shared__ uint32_t s_stack[kLdsStack * 256];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void k_megakernel(DeviceScene sc, Frame f, flo
         if (outline) pass = mk3(1.0f, 1.0f, 1.0f);
         for (uint32_t depth = 0; depth < f.max_bounces && !outline; depth++) {
             float t; uint32_t id; Counts cnt = {0, 0};
-            closest_hit<COUNT>(sc, o, d, s_stack + threadIdx.x, 256, t, id, cnt);
+            closest_hit<COUNT, ALPHA>(sc, o, d, s_stack + threadIdx.x, 256, t, id, cnt);
             rays++;
             if (COUNT) { nodes += cnt.nodes; prims += cnt.prims; }
             if (depth == 0) primary = id;
@@ -138,12 +139,13 @@ bool launch_megakernel(hipStream_t stream, const DeviceSceneHost &sch, const Fra
     if (f.n_tiles == 0) return true;
     dim3 grid((f.n_tiles + 3) / 4), block(256);
     float4 *acc = (float4 *)accum;
-    if (fs.rng_mode == CRT_RNG_REF) {
-        if (fs.instrumented) hipLaunchKernelGGL((k_megakernel<0, true>), grid, block, 0, stream, sc, f, acc, hit_ids, stats);
-        else hipLaunchKernelGGL((k_megakernel<0, false>), grid, block, 0, stream, sc, f, acc, hit_ids, stats);
-    } else {
-        if (fs.instrumented) hipLaunchKernelGGL((k_megakernel<1, true>), grid, block, 0, stream, sc, f, acc, hit_ids, stats);
-        else hipLaunchKernelGGL((k_megakernel<1, false>), grid, block, 0, stream, sc, f, acc, hit_ids, stats);
+    // (rng, instrumented, alpha test): the alpha-tested variants exist only as separate kernels (intersect.h test_leaf)
+    const int variant = (fs.rng_mode == CRT_RNG_REF ? 0 : 4) | (fs.instrumented ? 2 : 0) | ((sc.ext & CRT_EXT_ALPHA_TEST) ? 1 : 0);
+    switch (variant) {
+#define CRT_MEGA(V, R, C, A) case V: hipLaunchKernelGGL((k_megakernel<R, C, A>), grid, block, 0, stream, sc, f, acc, hit_ids, stats); break;
+        CRT_MEGA(0, 0, false, false) CRT_MEGA(1, 0, false, true) CRT_MEGA(2, 0, true, false) CRT_MEGA(3, 0, true, true)
+        CRT_MEGA(4, 1, false, false) CRT_MEGA(5, 1, false, true) CRT_MEGA(6, 1, true, false) CRT_MEGA(7, 1, true, true)
+#undef CRT_MEGA
     }
     HIP_TRY(hipGetLastError());
     return true;
@@ -275,7 +277,7 @@ template <bool SPILL> struct LaneTrav<false, SPILL> {          // sibling-pair B
     CRT_DEV void begin(V3 o, V3 d) { trav_begin(tr, o, d); }
     CRT_DEV bool at_leaf() const { return (tr.cur & kLeafTag) != 0; }
     template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, const uint8_t *, Entry *stack, Entry *spill, int depth, Counts &c) { return trav_inner<COUNT>(sc, tr, stack, 256, spill, depth, c); }
-    template <bool COUNT> CRT_DEV bool leaf(const DeviceScene &sc, const uint8_t *, Entry *stack, Entry *spill, int depth, Counts &c) { return trav_leaf<COUNT>(sc, tr, stack, 256, spill, depth, c); }
+    template <bool COUNT, bool ALPHA> CRT_DEV bool leaf(const DeviceScene &sc, const uint8_t *, Entry *stack, Entry *spill, int depth, Counts &c) { return trav_leaf<COUNT, ALPHA>(sc, tr, stack, 256, spill, depth, c); }
 };
 template <bool SPILL> struct LaneTrav<true, SPILL> {           // 8-wide quantised BVH (intersect_wide.h)
     using Entry = uint2;
@@ -284,7 +286,7 @@ template <bool SPILL> struct LaneTrav<true, SPILL> {           // 8-wide quantis
     CRT_DEV void begin(V3 o, V3 d) { wide_begin(tr, o, d); }
     CRT_DEV bool at_leaf() const { return (tr.cur & kLeafTag) != 0; }
     template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, const uint8_t *order, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_inner<COUNT, SPILL>(sc.wide, order, tr, stack, 256, spill, depth, c); }
-    template <bool COUNT> CRT_DEV bool leaf(const DeviceScene &sc, const uint8_t *order, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_leaf<COUNT, SPILL>(sc, order, tr, stack, 256, spill, depth, c); }
+    template <bool COUNT, bool ALPHA> CRT_DEV bool leaf(const DeviceScene &sc, const uint8_t *order, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_leaf<COUNT, SPILL, ALPHA>(sc, order, tr, stack, 256, spill, depth, c); }
 };
 static_assert(kLdsStack * 4 == kWideLds * 8, "both stack layouts use the same LDS block");
 
@@ -293,7 +295,9 @@ static_assert(kLdsStack * 4 == kWideLds * 8, "both stack layouts use the same LD
 #endif
 // QUERY (crt_rays_query): 0 = path segments; 1 = caller's rays, closest hit in (t_near, t_max] (t_max rides in ray_o.w);
 // 2 = same interval, any hit: a lane stops at the first primitive it finds.
-template <bool COUNT, bool WIDE, bool SPILL, int QUERY = 0>
+// ALPHA: the CRT_EXT_ALPHA_TEST variant of the triangle test (always with SPILL: the extension's kernels are not the
+// headline path and one stack layout keeps their number down).
+template <bool COUNT, bool WIDE, bool SPILL, int QUERY = 0, bool ALPHA = false>
 __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene sc, WfQueues q, uint32_t bounce, unsigned long long dead, DeviceStats *stats) {
     __shared__ uint2 s_stack[kWideLds * 256];
     __shared__ uint8_t s_order[WIDE ? kWideOrderBytes : 4];
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
         bool more = true;
         if (n_leaf >= q.leaf_lanes || !any_inner) {
             if (COUNT) { c_leaf++; c_leaf_lanes += n_leaf; }
-            if (at_leaf) more = lt.template leaf<COUNT>(sc, s_order, stack, spill, lds_depth, cnt);
+            if (at_leaf) more = lt.template leaf<COUNT, ALPHA>(sc, s_order, stack, spill, lds_depth, cnt);
         } else {
             if (COUNT) { c_inner++; c_inner_lanes += (uint32_t)__popcll(__ballot(busy && !at_leaf)); }
             if (busy && !at_leaf) more = lt.template inner<COUNT>(sc, s_order, stack, spill, lds_depth, cnt);
@@ -515,6 +519,31 @@ static bool ensure_dev(DeviceBuffer &b, size_t bytes, std::string &err) {
     return true;
 }
 
+// One place that picks the k_wf_extend instantiation.  wide/spill as launch_wavefront decides them; alpha (the
+// CRT_EXT_ALPHA_TEST kernels) always takes the SPILL layout; queries are never instrumented.
+template <int QUERY>
+static void launch_extend(bool count, bool wide, bool spill, bool alpha, dim3 grid, hipStream_t stream, const DeviceScene &sc,
+                          const WfQueues &q, uint32_t bounce, unsigned long long dead, DeviceStats *stats) {
+    const dim3 block(256);
+    if (alpha || !wide) spill = true;
+    if (QUERY != 0) count = false;
+    const int variant = (count ? 8 : 0) | (wide ? 4 : 0) | (spill ? 2 : 0) | (alpha ? 1 : 0);
+    switch (variant) {
+#define CRT_EXT_CASE(V, C, W, S, A) case V: hipLaunchKernelGGL((k_wf_extend<C, W, S, QUERY, A>), grid, block, 0, stream, sc, q, bounce, dead, stats); break;
+        CRT_EXT_CASE(2, false, false, true, false)  CRT_EXT_CASE(3, false, false, true, true)
+        CRT_EXT_CASE(4, false, true, false, false)  CRT_EXT_CASE(6, false, true, true, false)  CRT_EXT_CASE(7, false, true, true, true)
+        default: break;
+    }
+    if constexpr (QUERY == 0) {
+        switch (variant) {
+            CRT_EXT_CASE(10, true, false, true, false)  CRT_EXT_CASE(11, true, false, true, true)
+            CRT_EXT_CASE(12, true, true, false, false)  CRT_EXT_CASE(14, true, true, true, false)  CRT_EXT_CASE(15, true, true, true, true)
+            default: break;
+        }
+    }
+#undef CRT_EXT_CASE
+}
+
 bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const FrameSetup &fs, const crt_scene_params &params,
                       uint32_t n_batch, const float *seeds, WavefrontState &wf, float *accum, uint32_t accum_pixels,
                       uint32_t *hit_ids, DeviceStats *stats, std::string &err) {
@@ -584,16 +613,9 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
             HIP_TRY(hipEventRecord(wf.ev[wf.ev_used], stream));
         }
         q.lds_depth = fs.small_stack ? 1u : (sc.wide ? (uint32_t)kWideLds : (uint32_t)kLdsStack);
-        if (sc.wide && sch.wide_levels <= q.lds_depth + 1u) {      // at most levels - 1 groups wait on the stack
-            if (fs.instrumented) hipLaunchKernelGGL((k_wf_extend<true, true, false>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
-            else hipLaunchKernelGGL((k_wf_extend<false, true, false>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
-        } else if (sc.wide) {
-            if (fs.instrumented) hipLaunchKernelGGL((k_wf_extend<true, true, true>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
-            else hipLaunchKernelGGL((k_wf_extend<false, true, true>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
-        } else {
-            if (fs.instrumented) hipLaunchKernelGGL((k_wf_extend<true, false, true>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
-            else hipLaunchKernelGGL((k_wf_extend<false, false, true>), pgrid, block, 0, stream, sc, q, b, dead_b, stats);
-        }
+        // wide trees of at most lds_depth + 1 levels never overflow the LDS stack (at most levels - 1 groups wait on it)
+        launch_extend<0>(fs.instrumented, sc.wide != nullptr, !(sc.wide && sch.wide_levels <= q.lds_depth + 1u), (sc.ext & CRT_EXT_ALPHA_TEST) != 0,
+                         pgrid, stream, sc, q, b, dead_b, stats);
         if (wf.time_kernels) HIP_TRY(hipEventRecord(wf.ev[wf.ev_used + 1], stream));
         if (pcg) hipLaunchKernelGGL((k_wf_shade<1>), sgrid, block, 0, stream, sc, f, q, b, (float4 *)wf.pass.ptr, accum_pixels, hit_ids);
         else hipLaunchKernelGGL((k_wf_shade<0>), sgrid, block, 0, stream, sc, f, q, b, (float4 *)wf.pass.ptr, accum_pixels, hit_ids);
@@ -660,16 +682,9 @@ bool launch_ray_query(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     hipLaunchKernelGGL(k_query_init, dim3(1), dim3(256), 0, stream, q, n_rays);
     hipLaunchKernelGGL(k_query_pack, dim3((n_rays + 255) / 256), block, 0, stream, q, (const crt_ray *)wf.query_rays.ptr, n_rays);
     const bool any = mode == CRT_QUERY_ANY;
-    if (sc.wide && sch.wide_levels <= q.lds_depth + 1u) {
-        if (any) hipLaunchKernelGGL((k_wf_extend<false, true, false, 2>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
-        else hipLaunchKernelGGL((k_wf_extend<false, true, false, 1>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
-    } else if (sc.wide) {
-        if (any) hipLaunchKernelGGL((k_wf_extend<false, true, true, 2>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
-        else hipLaunchKernelGGL((k_wf_extend<false, true, true, 1>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
-    } else {
-        if (any) hipLaunchKernelGGL((k_wf_extend<false, false, true, 2>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
-        else hipLaunchKernelGGL((k_wf_extend<false, false, true, 1>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
-    }
+    const bool spill = !(sc.wide && sch.wide_levels <= q.lds_depth + 1u), alpha = (sc.ext & CRT_EXT_ALPHA_TEST) != 0;
+    if (any) launch_extend<2>(false, sc.wide != nullptr, spill, alpha, pgrid, stream, sc, q, 0u, 0ull, stats);
+    else launch_extend<1>(false, sc.wide != nullptr, spill, alpha, pgrid, stream, sc, q, 0u, 0ull, stats);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hits, wf.hit.ptr, (size_t)n_rays * sizeof(crt_ray_hit), hipMemcpyDefault, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -741,16 +756,9 @@ bool launch_ray_query_noalloc(hipStream_t stream, int device, const DeviceSceneH
     hipLaunchKernelGGL(k_query_init, dim3(1), dim3(256), 0, stream, q, n_rays);
     hipLaunchKernelGGL(k_query_pack, dim3((n_rays + 255) / 256), block, 0, stream, q, rays_dev, n_rays);
     const bool any = mode == CRT_QUERY_ANY;
-    if (sc.wide && sch.wide_levels <= q.lds_depth + 1u) {
-        if (any) hipLaunchKernelGGL((k_wf_extend<false, true, false, 2>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
-        else hipLaunchKernelGGL((k_wf_extend<false, true, false, 1>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
-    } else if (sc.wide) {
-        if (any) hipLaunchKernelGGL((k_wf_extend<false, true, true, 2>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
-        else hipLaunchKernelGGL((k_wf_extend<false, true, true, 1>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
-    } else {
-        if (any) hipLaunchKernelGGL((k_wf_extend<false, false, true, 2>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
-        else hipLaunchKernelGGL((k_wf_extend<false, false, true, 1>), pgrid, block, 0, stream, sc, q, 0u, 0ull, stats);
-    }
+    const bool spill = !(sc.wide && sch.wide_levels <= q.lds_depth + 1u), alpha = (sc.ext & CRT_EXT_ALPHA_TEST) != 0;
+    if (any) launch_extend<2>(false, sc.wide != nullptr, spill, alpha, pgrid, stream, sc, q, 0u, 0ull, stats);
+    else launch_extend<1>(false, sc.wide != nullptr, spill, alpha, pgrid, stream, sc, q, 0u, 0ull, stats);
     HIP_TRY(hipGetLastError());
     return true;
 }

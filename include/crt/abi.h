@@ -62,6 +62,14 @@ int crt_scene_upload(crt_context *ctx, const crt_scene_desc *scene);
  * 16 bounces; CRT_BVH_WIDE up to 2^24 - 1 primitives and 64 levels; a wavefront batch needs fewer than 2^26 - 1
  * pixels per context (larger frames render one iteration per launch sequence). */
 
+/* Build extensions (CRT_EXT_* of types.h).  No counterpart in the reference: its shader ignores
+ * RTMaterial::GPU_t::textureIndex (compute.comp:386-387 reads textures[0]) and has no alpha test; SURVEY section 7
+ * lists both as extensions of this build, off by default.  Takes effect from the next dispatch / query; may be called
+ * before or after crt_scene_upload.  CRT_EXT_TEXTURE_INDEX needs every material's textureIndex to be CRT_BAD_INDEX or
+ * below n_textures: the call (or a later crt_scene_upload) fails with CRT_ERR_INVALID otherwise.  Unknown bits are
+ * refused. */
+int crt_extensions_set(crt_context *ctx, uint32_t ext_flags);
+
 /* Replaces BVHNode::BVHNode + gpu_serialize on the host
  * (raytracing/src/bounding_volume_hierarchy.cpp:63-130) with a device-side
  * build over the uploaded primitives.  flags: CRT_BVH_*.  build_ms (optional)

@@ -168,6 +168,16 @@ enum {
                                       LDS stack) runs on every scene */
 };
 
+/* crt_extensions_set: build extensions with no counterpart in the reference, all off by default.
+ * With none set the renderer is the reference's shader bit for bit. */
+enum {
+    CRT_EXT_TEXTURE_INDEX = 1u << 0, /* a textured Lambertian samples textures[material.textureIndex]; the shader always
+                                        samples textures[0] whatever the index says (compute.comp:386-387) */
+    CRT_EXT_ALPHA_TEST    = 1u << 1  /* cut-out textures: a triangle hit whose material is textured counts only where the
+                                        texture's alpha, fetched like the colour (bilinear, REPEAT), is >= 0.5 at the hit's
+                                        (u, v); applies to paths, crt_rays_query closest and any-hit (shadow rays) alike */
+};
+
 typedef struct crt_config {
     uint32_t width, height;     /* accumulation image size (imageSize() in the shader) */
     uint32_t rng_mode;

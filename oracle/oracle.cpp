@@ -93,6 +93,9 @@ enum {
     // bits 8-15: band_world, bits 16-23: band_rank.  band_world > 1 renders only the 8-row bands b with
     // b % band_world == band_rank (the multi-GPU partition); the other rows of accum / ids stay untouched.
     ORC_BAND_WORLD_SHIFT = 8, ORC_BAND_RANK_SHIFT = 16,
+    // Build extensions (no counterpart in the reference; off by default, SURVEY section 7 / abi.h crt_extensions_set):
+    ORC_EXT_TEXTURE_INDEX = 1 << 24,   // a textured Lambertian samples textures[material.textureIndex] instead of textures[0]
+    ORC_EXT_ALPHA_TEST    = 1 << 25,   // a triangle hit whose material texture has alpha < 0.5 at the hit's (u, v) is no hit
 };
 
 // ------------------------------------------------------------------- vec3 ---
@@ -348,8 +351,31 @@ inline void hit_quad(const Ray &ray, const Quad &q, uint32_t id, bool canonical,
     rec.u = alpha; rec.v = beta;
 }
 
+// Build extension ORC_EXT_ALPHA_TEST: the alpha channel through the same sampler as the colour fetch (T8: RGBA8 UNORM,
+// bilinear, REPEAT, texel centres at +0.5, plain float weights in the order sample_texture uses).
+struct ExtCtx { const Scene *sc; bool tex_index, alpha_test; };
+inline float texture_alpha(const Texture &tx, float u, float v) {
+    float x = u * (float)tx.width - 0.5f, y = v * (float)tx.height - 0.5f;
+    float x0f = floorf(x), y0f = floorf(y);
+    float fx = x - x0f, fy = y - y0f;
+    auto wrap = [](float f, int n) { int i = (int)f % n; return i < 0 ? i + n : i; };
+    int x0 = wrap(x0f, (int)tx.width), y0 = wrap(y0f, (int)tx.height);
+    int x1 = x0 + 1 == (int)tx.width ? 0 : x0 + 1, y1 = y0 + 1 == (int)tx.height ? 0 : y0 + 1;
+    auto a = [&](int xx, int yy) { return (float)tx.rgba8[4 * ((size_t)yy * tx.width + (size_t)xx) + 3] / 255.0f; };
+    float top = a(x0, y0) * (1.0f - fx) + a(x1, y0) * fx;
+    float bot = a(x0, y1) * (1.0f - fx) + a(x1, y1) * fx;
+    return top * (1.0f - fy) + bot * fy;
+}
+// The texture a material samples: textures[0] in the reference (compute.comp:387), textures[textureIndex] with
+// ORC_EXT_TEXTURE_INDEX; null for an untextured material (or an index past the array, which the device refuses at upload).
+inline const Texture *material_texture(const Scene &sc, const Material &m, bool tex_index) {
+    if (m.textureIndex == BAD_INDEX || sc.n_textures == 0) return nullptr;
+    if (!tex_index) return &sc.textures[0];
+    return m.textureIndex < sc.n_textures ? &sc.textures[m.textureIndex] : nullptr;
+}
+
 // compute.comp:280-315
-inline void hit_tri(const Ray &ray, const Tri &tr, uint32_t id, bool canonical, Hit &rec) {
+inline void hit_tri(const Ray &ray, const Tri &tr, uint32_t id, bool canonical, Hit &rec, const ExtCtx *ext = nullptr) {
     V3 v0 = v3(tr.v0);
     V3 e10 = v3(tr.v1) - v0;
     V3 e20 = v3(tr.v2) - v0;
@@ -364,16 +390,22 @@ inline void hit_tri(const Ray &ray, const Tri &tr, uint32_t id, bool canonical, 
     float invDet = 1.0f / det;
     float t = dot(e20, q) * invDet;
     if (!accept(canonical, t, id, rec)) return;
+    beta = beta * invDet;
+    gamma = gamma * invDet;
+    float alpha = 1.0f - beta - gamma;
+    const float u = (alpha * tr.u[0] + beta * tr.u[1]) + gamma * tr.u[2];
+    const float v = (alpha * tr.v[0] + beta * tr.v[1]) + gamma * tr.v[2];
+    if (ext && ext->alpha_test) {                 // build extension: a cut-out texel lets the ray through
+        const Texture *tx = material_texture(*ext->sc, ext->sc->materials[tr.materialIndex], ext->tex_index);
+        if (tx && texture_alpha(*tx, u, v) < 0.5f) return;
+    }
     rec.t = t; rec.id = id;
     rec.position = ray.o + rec.t * ray.d;
     V3 outward = cross(e20, e10);                 // not normalised (sic)
     set_face_normal(ray, outward, rec);
     rec.materialIndex = tr.materialIndex;
-    beta = beta * invDet;
-    gamma = gamma * invDet;
-    float alpha = 1.0f - beta - gamma;
-    rec.u = (alpha * tr.u[0] + beta * tr.u[1]) + gamma * tr.u[2];
-    rec.v = (alpha * tr.v[0] + beta * tr.v[1]) + gamma * tr.v[2];
+    rec.u = u;
+    rec.v = v;
 }
 
 // compute.comp:214-225.  min()/max() with a NaN operand (0 * inf) are undefined
@@ -592,6 +624,7 @@ struct World {
     Scene sc;
     int traverse;
     bool canonical;
+    ExtCtx ext{nullptr, false, false};      // build extensions (ORC_EXT_*); ext.sc points at this->sc
     // input-id list in slot order for BRUTE/FAST
     std::vector<uint32_t> all_ids;
     FastBVH fast;
@@ -608,7 +641,7 @@ inline void test_prim(const World &w, const Ray &ray, uint32_t id, Hit &rec, Cou
     uint32_t kind = id >> 30, i = id & 0x3FFFFFFFu;
     if (kind == KIND_SPHERE) hit_sphere(ray, w.sc.spheres[i], id, w.canonical, rec);
     else if (kind == KIND_QUAD) hit_quad(ray, w.sc.quads[i], id, w.canonical, rec);
-    else hit_tri(ray, w.sc.tris[i], id, w.canonical, rec);
+    else hit_tri(ray, w.sc.tris[i], id, w.canonical, rec, &w.ext);
 }
 
 inline bool slab_double(const double lo[3], const double hi[3], const Ray &ray, const double inv[3], double tmax) {
@@ -745,7 +778,8 @@ bool scatter(const World &w, Ray &ray, const Hit &rec, V3 &attenuation, Rng &rng
             V3 dir = rec.normal + random_in_unit_sphere(rng);
             ray = Ray{rec.position, normalize(dir)};
             // :385-389 -- always samples textures[0], whatever textureIndex says (sic)
-            if (m.textureIndex != BAD_INDEX && w.sc.n_textures > 0) attenuation = sample_texture(w.sc.textures[0], rec.u, rec.v);
+            // (ORC_EXT_TEXTURE_INDEX, a build extension, honours the index)
+            if (const Texture *tx = material_texture(w.sc, m, w.ext.tex_index)) attenuation = sample_texture(*tx, rec.u, rec.v);
             return true;
         }
         case MAT_METAL: {
@@ -841,6 +875,7 @@ void world_init(World &w, const Scene &sc, int flags) {
     w.sc = sc;
     w.traverse = flags & ORC_TRAVERSE_MASK;
     w.canonical = w.traverse != ORC_TRAVERSE_REF;
+    w.ext = ExtCtx{&w.sc, (flags & ORC_EXT_TEXTURE_INDEX) != 0, (flags & ORC_EXT_ALPHA_TEST) != 0};
     for (uint32_t i = 0; i < sc.n_spheres; i++) w.all_ids.push_back((KIND_SPHERE << 30) | i);
     for (uint32_t i = 0; i < sc.n_quads; i++) w.all_ids.push_back((KIND_QUAD << 30) | i);
     for (uint32_t i = 0; i < sc.n_tris; i++) w.all_ids.push_back(((uint32_t)KIND_TRI << 30) | i);

@@ -14,6 +14,7 @@ LIB = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
 
 TRAVERSE_BRUTE, TRAVERSE_FAST, TRAVERSE_REF, TRAVERSE_BUILD = 0, 1, 2, 3
 RNG_PCG, FULL_IMAGE, LIBM = 1 << 4, 1 << 5, 1 << 6
+EXT_TEXTURE_INDEX, EXT_ALPHA_TEST = 1 << 24, 1 << 25      # the build's extensions (abi.h crt_extensions_set)
 
 
 def BANDS(rank, world):
