@@ -138,44 +138,65 @@ __device__ __forceinline__ unsigned long long wave_sort(unsigned long long key, 
     return key;
 }
 
-// One wave builds the whole subtree of a node with at most kWaveNode items, level by level.  Lane l holds the item at
-// position a + l of the permutation; the nodes of the current level are segments [s0, s1) of consecutive lanes and
-// every lane carries its segment's bookkeeping.  Per level and axis: sort the lanes by (segment, centroid), which
-// orders each segment in place; segmented prefix / suffix scans of the boxes then price every split of every segment
-// at once (exact sweep SAH: each item's centroid is a candidate plane).  The cheapest (axis, rank) of a segment is
-// found with a segmented min-scan, the segment is left in that axis's order and cut there.
+// One wave builds the whole subtree of a node with at most kWaveNode items, level by level.  Item j of the node lives in
+// lane j for good (its box, kind and LDS index: the "home" lane).  What moves are three permutations, one per axis:
+// ord[ax] of lane l = the item at position l when every open node's items are in ascending centroid order on that axis.
+// The nodes of the current level are segments [s0, s1) of consecutive POSITIONS, the same in all three orders, and every
+// lane carries the bookkeeping of the segment its position belongs to.  Per level and axis: fetch the boxes in that
+// axis's order, segmented prefix / suffix scans of the boxes price every split of every segment at once (exact sweep
+// SAH: each item's centroid is a candidate plane).  The cheapest (axis, rank) of a segment is found with a segmented
+// min-scan; the items left of it are flagged at their home lanes and all three orders are partitioned stably
+// (ballot + prefix count + one ds_permute each), which keeps each side sorted on every axis.  The orders are therefore
+// sorted once, up front: re-sorting every level (three 21-stage bitonic networks) was two thirds of this function's
+// dependent shuffles.
+__device__ __forceinline__ uint32_t lane_push(uint32_t to_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_permute((int)(to_lane << 2), (int)v); }
+__device__ __forceinline__ uint32_t lane_pull(uint32_t from_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)v); }
+
 __device__ void sah_wave_subtree(const SahGroupArgs &g, SahLds &L, uint32_t group, uint32_t gs, uint32_t pair_base, uint2 e, uint32_t lane) {
     const uint32_t ex = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
     const uint32_t a = ex & 0xFFFFu, k = (ex >> 16) - a;
     const bool act = lane < k;
-    uint32_t it = act ? L.idx[a + lane] : 0u;
+    // home data of item `lane`
+    const uint32_t it = act ? L.idx[a + lane] : 0u;
     float lo[3], hi[3];
 #pragma unroll
     for (int ax = 0; ax < 3; ax++) { lo[ax] = act ? L.box[ax][it] : kFInf; hi[ax] = act ? L.box[3 + ax][it] : -kFInf; }
-    uint32_t kind = (g.level0 && act) ? (uint32_t)L.kind[it] : 0u;
-    uint32_t s0 = act ? 0u : lane, s1 = act ? k : lane + 1u;         // lanes past k: closed one-lane segments that stay put
+    const uint32_t kind = (g.level0 && act) ? (uint32_t)L.kind[it] : 0u;
+    uint32_t ord[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {      // lanes past k sort behind the items, in lane order: they keep ord = lane
+        const float c = 0.5f * lo[ax] + 0.5f * hi[ax];
+        const unsigned long long key = act ? (((unsigned long long)enc_f(c) << 8) | lane) : ((1ull << 40) | lane);
+        ord[ax] = (uint32_t)wave_sort(key, lane) & 63u;
+    }
+    uint32_t s0 = act ? 0u : lane, s1 = act ? k : lane + 1u;         // positions past k: closed one-lane segments that stay put
     uint32_t y = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);  // p | pp << 11 | side << 22 | root << 23 of my segment
     bool open = act;
     for (;;) {
+        // the items in axis-0 order: that order is the final one (links of single items and leaves are positions)
+        float blo[3], bhi[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) { blo[d] = __shfl(lo[d], (int)ord[0]); bhi[d] = __shfl(hi[d], (int)ord[0]); }
+        const uint32_t kind_p = lane_pull(ord[0], kind), it_p = lane_pull(ord[0], it);
         if (open && s1 - s0 == 1u) {                                  // a single item: its descriptor, done
             uint32_t link, count;
-            if (g.level0) { link = gs + a + lane; count = (kind << 28) | 1u; }       // link = final position, patched to the kind's slot later
-            else { link = __float_as_uint(g.desc_in[2 * (size_t)(gs + it)].w); count = __float_as_uint(g.desc_in[2 * (size_t)(gs + it) + 1].w); }
-            put_desc(g, group, pair_base, y, lo, hi, link, count);
+            if (g.level0) { link = gs + a + lane; count = (kind_p << 28) | 1u; }       // link = final position, patched to the kind's slot later
+            else { link = __float_as_uint(g.desc_in[2 * (size_t)(gs + it_p)].w); count = __float_as_uint(g.desc_in[2 * (size_t)(gs + it_p) + 1].w); }
+            put_desc(g, group, pair_base, y, blo, bhi, link, count);
             open = false;
         }
         if (__ballot(open) == 0ull) break;
         const uint32_t len = s1 - s0;
         float best = kFInf, nlo[3], nhi[3];
-        uint32_t best_ax = 0, src[3];
+        uint32_t best_ax = 0;
 #pragma unroll
         for (int ax = 0; ax < 3; ax++) {
-            const float c = 0.5f * lo[ax] + 0.5f * hi[ax];
-            const unsigned long long key = wave_sort(((unsigned long long)s0 << 40) | ((unsigned long long)enc_f(c) << 8) | lane, lane);
-            src[ax] = (uint32_t)key & 63u;
             float llo[3], lhi[3], rlo[3], rhi[3];
 #pragma unroll
-            for (int d = 0; d < 3; d++) { llo[d] = rlo[d] = __shfl(lo[d], (int)src[ax]); lhi[d] = rhi[d] = __shfl(hi[d], (int)src[ax]); }
+            for (int d = 0; d < 3; d++) {
+                llo[d] = rlo[d] = ax == 0 ? blo[d] : __shfl(lo[d], (int)ord[ax]);
+                lhi[d] = rhi[d] = ax == 0 ? bhi[d] : __shfl(hi[d], (int)ord[ax]);
+            }
 #pragma unroll
             for (uint32_t off = 1; off < 64; off <<= 1) {             // inclusive scans inside the segment: left box up to me, right box from me
                 const bool tl = lane >= s0 + off, tr = lane + off < s1;
@@ -204,12 +225,12 @@ __device__ void sah_wave_subtree(const SahGroupArgs &g, SahLds &L, uint32_t grou
         bk = __shfl(bk, (int)(s1 - 1u));
         const float split_cost = __uint_as_float((uint32_t)(bk >> 32));
         const bool valid = split_cost < kFInf;
-        const uint32_t bax = ((uint32_t)bk >> 8) & 3u;
-        uint32_t nl = valid ? ((uint32_t)bk & 63u) - s0 + 1u : len / 2u;         // no finite candidate: halve the current order
+        const uint32_t bax = valid ? ((uint32_t)bk >> 8) & 3u : 0u;            // no finite candidate: halve the axis-0 order
+        const uint32_t nl = valid ? ((uint32_t)bk & 63u) - s0 + 1u : len / 2u;
         // multi-primitive leaf?  (level 0, one kind, at most max_leaf primitives, not more expensive than the split)
         bool leaf = false;
-        const uint32_t kind0 = (uint32_t)__shfl((int)kind, (int)s0);
-        const unsigned long long mism = __ballot(open && kind != kind0);
+        const uint32_t kind0 = (uint32_t)__shfl((int)kind_p, (int)s0);
+        const unsigned long long mism = __ballot(open && kind_p != kind0);
         // The root of the whole tree is never closed as a leaf: it has no descriptor slot (put_desc drops it), and pair 0
         // would keep its all-zero memset, i.e. two "inner" children linking back to pair 0.  It always splits into pair 0.
         const bool tree_root = (y & kEntRoot) != 0u && g.desc_out == nullptr;
@@ -220,21 +241,30 @@ __device__ void sah_wave_subtree(const SahGroupArgs &g, SahLds &L, uint32_t grou
         }
         const uint32_t p = y & 0x7FFu;
         if (open && lane == s0) {
-            if (leaf) put_desc(g, group, pair_base, y, nlo, nhi, gs + a + s0, (kind << 28) | len);
+            if (leaf) put_desc(g, group, pair_base, y, nlo, nhi, gs + a + s0, (kind_p << 28) | len);
             else put_desc(g, group, pair_base, y, nlo, nhi, pair_base + p, 0u);
         }
         if (leaf) open = false;
-        // leave every split segment in its axis's order, then cut it
-        const uint32_t from = (open && valid) ? (bax == 0 ? src[0] : bax == 1 ? src[1] : src[2]) : lane;
-        it = (uint32_t)__shfl((int)it, (int)from); kind = (uint32_t)__shfl((int)kind, (int)from);
+        // Which items go left: position l of the winning axis's order holds one of the segment's items; tell its home lane.
+        // Closed segments (and lanes past k) flag everything "left" of a cut at their end, which leaves them in place.
+        const uint32_t cut = open ? s0 + nl : s1;
+        const uint32_t winner = !open ? ord[0] : bax == 0 ? ord[0] : bax == 1 ? ord[1] : ord[2];
+        const uint32_t left_home = lane_push(winner, lane < cut ? 1u : 0u);
+        const unsigned long long below = ((1ull << lane) - 1ull) & ~((1ull << s0) - 1ull);      // positions [s0, lane)
 #pragma unroll
-        for (int d = 0; d < 3; d++) { lo[d] = __shfl(lo[d], (int)from); hi[d] = __shfl(hi[d], (int)from); }
+        for (int ax = 0; ax < 3; ax++) {      // stable partition of every order
+            const bool left = lane_pull(ord[ax], left_home) != 0u;
+            const uint32_t before = (uint32_t)__popcll(__ballot(left) & below);
+            const uint32_t to = left ? s0 + before : cut + (lane - s0 - before);
+            ord[ax] = lane_push(to, ord[ax]);
+        }
         if (open) {
-            if (lane < s0 + nl) { s1 = s0 + nl; y = (p + 1u) | (p << 11); }
-            else { s0 = s0 + nl; y = (p + nl) | (p << 11) | (1u << 22); }
+            if (lane < cut) { s1 = cut; y = (p + 1u) | (p << 11); }
+            else { s0 = cut; y = (p + nl) | (p << 11) | (1u << 22); }
         }
     }
-    if (act) L.idx[a + lane] = (uint16_t)it;
+    const uint32_t it_final = lane_pull(ord[0], it);
+    if (act) L.idx[a + lane] = (uint16_t)it_final;
 }
 
 __device__ __forceinline__ int bin_of(float c, float cmin, float scale) {
