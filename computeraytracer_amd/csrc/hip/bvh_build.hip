@@ -34,6 +34,16 @@ __global__ void k_init_bounds(uint32_t *b) {
     else if (threadIdx.x < 6) b[threadIdx.x] = 0u;           // max
 }
 
+// Conservative padding: the slab test runs in fma form with rounded -o/d terms (intersect.h); 2^-18
+// of the coordinate magnitude is ~64 ulp, far above its error, far below any feature size.
+__device__ __forceinline__ void pad_box(float lo[3], float hi[3]) {
+    for (int a = 0; a < 3; a++) {
+        float m = fmaxf(fabsf(lo[a]), fabsf(hi[a]));
+        float p = m * 3.8146973e-6f + (hi[a] - lo[a]) * 9.5367432e-7f + 1e-30f;
+        lo[a] -= p; hi[a] += p;
+    }
+}
+
 __device__ __forceinline__ void prim_box(const BuildInput &in, uint32_t g, float lo[3], float hi[3]) {
     if (g < in.n_spheres) {
         const crt_sphere &s = in.spheres[g];
@@ -54,13 +64,7 @@ __device__ __forceinline__ void prim_box(const BuildInput &in, uint32_t g, float
         lo[1] = fminf(fminf(v0.y, v1.y), v2.y); hi[1] = fmaxf(fmaxf(v0.y, v1.y), v2.y);
         lo[2] = fminf(fminf(v0.z, v1.z), v2.z); hi[2] = fmaxf(fmaxf(v0.z, v1.z), v2.z);
     }
-    // Conservative padding: the slab test runs in fma form with rounded -o/d terms (intersect.h); 2^-18
-    // of the coordinate magnitude is ~64 ulp, far above its error, far below any feature size.
-    for (int a = 0; a < 3; a++) {
-        float m = fmaxf(fabsf(lo[a]), fabsf(hi[a]));
-        float p = m * 3.8146973e-6f + (hi[a] - lo[a]) * 9.5367432e-7f + 1e-30f;
-        lo[a] -= p; hi[a] += p;
-    }
+    pad_box(lo, hi);
 }
 
 // Shading record of triangle i (input order, 64 bytes = half a cache line, never straddling one): everything k_wf_shade
@@ -157,30 +161,31 @@ __global__ void k_kind_flags(uint32_t n, const uint32_t *vals, uint32_t ns, uint
     is_quad[s] = (g >= ns && g < ns + nq) ? 1u : 0u;
 }
 
-// Traversal records in sorted order.  leaf_link[s] = slot inside the kind's array, leaf_count[s] = kind << 28 | 1.
-__global__ void k_pack(BuildInput in, uint32_t n, const uint32_t *vals, const uint32_t *rank_sphere, const uint32_t *rank_quad,
-                       const float4 *tri_shade, float4 *tri_pack, float4 *sphere_pack, float4 *quad_pack, uint32_t *sphere_ids, uint32_t *quad_ids,
-                       uint32_t *tri_ids, uint32_t *leaf_link, uint32_t *leaf_count) {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
-    uint32_t g = vals[s];
+// Traversal record of sorted position s (primitive g) into its kind's array; returns the kind and the slot there.
+// WANT_BOX: also the primitive's padded box.  Spheres and quads: prim_box's own arithmetic on the record read here anyway.
+// Triangles: from the record's v0, v0 + e10, v0 + e20, i.e. corners at most an ulp from the uploaded ones, which is far
+// inside the 64-ulp pad and is the triangle the intersection test (which works from v0, e10, e20) sees.
+struct PackOut { float4 *tri_pack, *sphere_pack, *quad_pack; uint32_t *sphere_ids, *quad_ids, *tri_ids; };
+template <bool WANT_BOX>
+__device__ __forceinline__ void pack_prim(const BuildInput &in, uint32_t n, uint32_t s, uint32_t g, const uint32_t *rank_sphere, const uint32_t *rank_quad,
+                                          const float4 *tri_shade, const PackOut &out, uint32_t &kind, uint32_t &slot, float lo[3], float hi[3]) {
     // rank arrays are null when the scene holds one kind of primitive: every sorted position is that kind's slot
     uint32_t rs = rank_sphere ? rank_sphere[s] : (in.n_spheres == n ? s : 0u), rq = rank_quad ? rank_quad[s] : (in.n_quads == n ? s : 0u);
     if (g < in.n_spheres) {
         const crt_sphere &sp = in.spheres[g];
-        sphere_pack[rs] = make_float4(sp.center[0], sp.center[1], sp.center[2], sp.radius);
-        sphere_ids[rs] = g;
-        leaf_link[s] = rs; leaf_count[s] = (CRT_ID_KIND_SPHERE << 28) | 1u;
+        out.sphere_pack[rs] = make_float4(sp.center[0], sp.center[1], sp.center[2], sp.radius);
+        out.sphere_ids[rs] = g;
+        kind = CRT_ID_KIND_SPHERE; slot = rs;
     } else if (g < in.n_spheres + in.n_quads) {
         uint32_t i = g - in.n_spheres;
         const crt_quad &q = in.quads[i];
-        float4 *o = quad_pack + 4 * (size_t)rq;
+        float4 *o = out.quad_pack + 4 * (size_t)rq;
         o[0] = make_float4(q.normal[0], q.normal[1], q.normal[2], q.d);
         o[1] = make_float4(q.corner[0], q.corner[1], q.corner[2], q.u[0]);
         o[2] = make_float4(q.u[1], q.u[2], q.v[0], q.v[1]);
         o[3] = make_float4(q.v[2], q.w[0], q.w[1], q.w[2]);
-        quad_ids[rq] = i;
-        leaf_link[s] = rq; leaf_count[s] = (CRT_ID_KIND_QUAD << 28) | 1u;
+        out.quad_ids[rq] = i;
+        kind = CRT_ID_KIND_QUAD; slot = rq;
     } else {
         uint32_t i = g - in.n_spheres - in.n_quads;
         uint32_t rt = s - rs - rq;
@@ -188,13 +193,30 @@ __global__ void k_pack(BuildInput in, uint32_t n, const uint32_t *vals, const ui
         // the triangle's 64-byte shading record, written by k_prim_bounds: half a cache line instead of a 96-byte upload record
         const float4 *tp = tri_shade + 4 * (size_t)i;
         const float4 a = tp[0], b = tp[1], c = tp[2];
-        float4 *o = tri_pack + 3 * (size_t)rt;
+        float4 *o = out.tri_pack + 3 * (size_t)rt;
         o[0] = a;
         o[1] = b;
         o[2] = make_float4(c.x, __uint_as_float(CRT_MAKE_ID(CRT_ID_KIND_TRI, i)), 0.0f, 0.0f);
-        tri_ids[rt] = i;
-        leaf_link[s] = rt; leaf_count[s] = (CRT_ID_KIND_TRI << 28) | 1u;
+        out.tri_ids[rt] = i;
+        kind = CRT_ID_KIND_TRI; slot = rt;
+        if (WANT_BOX) {
+            const float v0[3] = {a.x, a.y, a.z}, v1[3] = {a.x + a.w, a.y + b.x, a.z + b.y}, v2[3] = {a.x + b.z, a.y + b.w, a.z + c.x};
+            for (int k = 0; k < 3; k++) { lo[k] = fminf(fminf(v0[k], v1[k]), v2[k]); hi[k] = fmaxf(fmaxf(v0[k], v1[k]), v2[k]); }
+            pad_box(lo, hi);
+        }
+        return;
     }
+    if (WANT_BOX) prim_box(in, g, lo, hi);
+}
+
+// SAH path (and n == 1): records only; leaf_link[s] = slot inside the kind's array, leaf_count[s] = kind << 28 | 1.
+__global__ void k_pack(BuildInput in, uint32_t n, const uint32_t *vals, const uint32_t *rank_sphere, const uint32_t *rank_quad,
+                       const float4 *tri_shade, PackOut out, uint32_t *leaf_link, uint32_t *leaf_count) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    uint32_t kind, slot; float lo[3], hi[3];
+    pack_prim<false>(in, n, s, vals[s], rank_sphere, rank_quad, tri_shade, out, kind, slot, lo, hi);
+    leaf_link[s] = slot; leaf_count[s] = (kind << 28) | 1u;
 }
 
 // delta(i, j): length of the common prefix of keys i and j, ties broken by the index (Karras 2012, section 4).
@@ -242,7 +264,7 @@ __global__ void k_hierarchy(int n, const uint64_t *keys, uint32_t *child_l, uint
 // (contiguous) range in sorted order, and whether the subtree is emitted as one multi-primitive leaf.
 constexpr uint32_t kMixed = 0xFFu;
 constexpr uint32_t kCollapsed = 0x100u;
-struct Sub { uint32_t count; float cost; uint32_t kind_flags; uint32_t first; };
+struct Sub { uint32_t count; float cost; uint32_t kind_flags; uint32_t first; };      // first = slot of the range's first primitive in its kind's array
 
 __device__ __forceinline__ float4 sub_pack(Sub s) {
     return make_float4(__uint_as_float(s.count), s.cost, __uint_as_float(s.kind_flags), __uint_as_float(s.first));
@@ -253,10 +275,9 @@ __device__ __forceinline__ Sub sub_unpack(float4 v) {
 
 // Child record inside its parent's pair: an inner child links to its own pair, a leaf (single primitive or a
 // collapsed subtree) to its first slot in the kind's sorted array.
-__device__ __forceinline__ void write_child(float4 *pair_half, int n, uint32_t child, float4 lo, float4 hi, Sub sub,
-                                            const uint32_t *leaf_link) {
+__device__ __forceinline__ void write_child(float4 *pair_half, int n, uint32_t child, float4 lo, float4 hi, Sub sub) {
     uint32_t link, count;
-    if (child >= (uint32_t)(n - 1) || (sub.kind_flags & kCollapsed)) { link = leaf_link[sub.first]; count = ((sub.kind_flags & 0xFFu) << 28) | sub.count; }
+    if (child >= (uint32_t)(n - 1) || (sub.kind_flags & kCollapsed)) { link = sub.first; count = ((sub.kind_flags & 0xFFu) << 28) | sub.count; }
     else { link = child; count = 0u; }
     pair_half[0] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(link));
     pair_half[1] = make_float4(hi.x, hi.y, hi.z, __uint_as_float(count));
@@ -287,8 +308,9 @@ constexpr uint32_t kRefitCap = 256;        // continuation entries per workgroup
 
 struct RefitArgs {
     int n;
-    const uint32_t *vals; const float4 *plo, *phi;
-    const uint32_t *child_l, *child_r, *parent, *range_lo, *range_hi, *leaf_link, *leaf_count;
+    const uint32_t *vals;
+    BuildInput in; const uint32_t *rank_sphere, *rank_quad; const float4 *tri_shade; PackOut out;      // stage 1 packs the leaves' records on the way
+    const uint32_t *child_l, *child_r, *parent, *range_lo, *range_hi;
     float4 *nlo, *nhi, *ninfo; uint32_t *flags; float4 *pairs;
     uint32_t max_leaf; float c_isect, c_trav;
 };
@@ -316,8 +338,8 @@ __device__ __forceinline__ void refit_climb(const RefitArgs &A, uint32_t node, f
         const float4 l_lo = mine_left ? lo : slo, l_hi = mine_left ? hi : shi;
         const float4 r_lo = mine_left ? slo : lo, r_hi = mine_left ? shi : hi;
         const Sub l_sub = mine_left ? sub : ssub, r_sub = mine_left ? ssub : sub;
-        write_child(A.pairs + 4 * (size_t)p, n, cl, l_lo, l_hi, l_sub, A.leaf_link);
-        write_child(A.pairs + 4 * (size_t)p + 2, n, cr, r_lo, r_hi, r_sub, A.leaf_link);
+        write_child(A.pairs + 4 * (size_t)p, n, cl, l_lo, l_hi, l_sub);
+        write_child(A.pairs + 4 * (size_t)p + 2, n, cr, r_lo, r_hi, r_sub);
         lo = make_float4(fminf(l_lo.x, r_lo.x), fminf(l_lo.y, r_lo.y), fminf(l_lo.z, r_lo.z), 0.0f);
         hi = make_float4(fmaxf(l_hi.x, r_hi.x), fmaxf(l_hi.y, r_hi.y), fmaxf(l_hi.z, r_hi.z), 0.0f);
         const float area = half_area(lo, hi);
@@ -335,40 +357,54 @@ __device__ __forceinline__ void refit_climb(const RefitArgs &A, uint32_t node, f
     }
 }
 
-// Stage 1: one thread per leaf.  Everything a climber hands to its sibling inside the workgroup's range stays in LDS
+// Stage 1: one thread per leaf, which first writes the leaf's traversal record (pack_prim).  Everything a climber hands to its sibling inside the workgroup's range stays in LDS
 // (an inner node whose range lies in [blk_lo, blk_hi] has its own index in that interval: a Karras node sits at one
 // end of its range), so a level costs one round of independent global loads (parent, range, children) plus the
 // 128 bytes of the pair it emits; only parked nodes are written to the global node arrays for the next stage.
 __global__ __launch_bounds__(kRefitLeaves) void k_refit_leaves(RefitArgs A, uint32_t *list_out, uint32_t *count_out) {
     __shared__ float4 s_lo[2 * kRefitLeaves], s_hi[2 * kRefitLeaves], s_info[2 * kRefitLeaves];      // [0, 256): inner nodes, [256, 512): leaves
     __shared__ uint32_t s_flag[kRefitLeaves];
+    __shared__ uint32_t s_parent[kRefitLeaves], s_rlo[kRefitLeaves], s_rhi[kRefitLeaves], s_cl[kRefitLeaves], s_cr[kRefitLeaves];
     __shared__ uint32_t s_count;
-    if (threadIdx.x == 0) s_count = 0;
-    s_flag[threadIdx.x] = 0;
-    __syncthreads();
     const uint32_t blk_lo = blockIdx.x * kRefitLeaves, blk_hi = blk_lo + kRefitLeaves - 1u;
     const uint32_t j = blk_lo + threadIdx.x;
     const int n = A.n;
+    if (threadIdx.x == 0) s_count = 0;
+    s_flag[threadIdx.x] = 0;
+    // The topology of the inner nodes whose index lies in this block's interval, in one round of coalesced loads: every
+    // node the climb below may enter is one of them, so a level costs LDS reads only (it used to be two dependent global
+    // loads per level and climber, which made this kernel latency-bound: 698 us at 10 M leaves).
+    if (j < (uint32_t)(n - 1)) {
+        s_parent[threadIdx.x] = A.parent[j]; s_rlo[threadIdx.x] = A.range_lo[j]; s_rhi[threadIdx.x] = A.range_hi[j];
+        s_cl[threadIdx.x] = A.child_l[j]; s_cr[threadIdx.x] = A.child_r[j];
+    }
+    __syncthreads();
     if (j < (uint32_t)n) {
         uint32_t node = (uint32_t)(n - 1) + j;
-        const uint32_t g = A.vals[j];
-        float4 lo = A.plo[g], hi = A.phi[g];
+        uint32_t p = A.parent[node];
+        // the leaf: its traversal record goes to its kind's array (k_pack's job on the SAH path) and its box comes from the
+        // same read, instead of a second gather of 2 x 16 bytes out of two more cache lines
+        uint32_t kind, slot; float blo[3], bhi[3];
+        pack_prim<true>(A.in, (uint32_t)n, j, A.vals[j], A.rank_sphere, A.rank_quad, A.tri_shade, A.out, kind, slot, blo, bhi);
+        float4 lo = make_float4(blo[0], blo[1], blo[2], 0.0f), hi = make_float4(bhi[0], bhi[1], bhi[2], 0.0f);
         Sub sub;
-        sub.count = 1; sub.kind_flags = A.leaf_count[j] >> 28; sub.first = j;
+        sub.count = 1; sub.kind_flags = kind; sub.first = slot;
         sub.cost = A.c_isect * half_area(lo, hi);
         s_lo[kRefitLeaves + threadIdx.x] = lo; s_hi[kRefitLeaves + threadIdx.x] = hi; s_info[kRefitLeaves + threadIdx.x] = sub_pack(sub);
         uint32_t *list = list_out + (size_t)blockIdx.x * kRefitCap;
         for (;;) {
-            const uint32_t p = A.parent[node];
             if (p == 0xFFFFFFFFu) break;                                   // node is the root
-            const uint32_t rl = A.range_lo[p], rh = A.range_hi[p], cl = A.child_l[p], cr = A.child_r[p];
-            if (rl < blk_lo || rh > blk_hi) {                              // the parent belongs to a later stage: park
+            // a node whose range lies inside the block has its own index inside it (a Karras node sits at one end of its range)
+            const uint32_t lp = p - blk_lo;
+            bool park = p < blk_lo || p > blk_hi;
+            uint32_t cl = 0, cr = 0;
+            if (!park) { cl = s_cl[lp]; cr = s_cr[lp]; park = s_rlo[lp] < blk_lo || s_rhi[lp] > blk_hi; }
+            if (park) {                                                    // the parent belongs to a later stage
                 A.nlo[node] = lo; A.nhi[node] = hi; A.ninfo[node] = sub_pack(sub);
                 const uint32_t k = atomicAdd(&s_count, 1u);
                 if (k < kRefitCap) list[k] = node;
                 break;
             }
-            const uint32_t lp = p - blk_lo;
             // only LDS data changes hands here: fence the local address space alone, the pair stores stay in flight
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             const uint32_t old = __hip_atomic_fetch_add(&s_flag[lp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -382,8 +418,8 @@ __global__ __launch_bounds__(kRefitLeaves) void k_refit_leaves(RefitArgs A, uint
             const float4 l_lo = mine_left ? lo : slo, l_hi = mine_left ? hi : shi;
             const float4 r_lo = mine_left ? slo : lo, r_hi = mine_left ? shi : hi;
             const Sub l_sub = mine_left ? sub : ssub, r_sub = mine_left ? ssub : sub;
-            write_child(A.pairs + 4 * (size_t)p, n, cl, l_lo, l_hi, l_sub, A.leaf_link);
-            write_child(A.pairs + 4 * (size_t)p + 2, n, cr, r_lo, r_hi, r_sub, A.leaf_link);
+            write_child(A.pairs + 4 * (size_t)p, n, cl, l_lo, l_hi, l_sub);
+            write_child(A.pairs + 4 * (size_t)p + 2, n, cr, r_lo, r_hi, r_sub);
             lo = make_float4(fminf(l_lo.x, r_lo.x), fminf(l_lo.y, r_lo.y), fminf(l_lo.z, r_lo.z), 0.0f);
             hi = make_float4(fmaxf(l_hi.x, r_hi.x), fmaxf(l_hi.y, r_hi.y), fmaxf(l_hi.z, r_hi.z), 0.0f);
             const float area = half_area(lo, hi);
@@ -398,6 +434,7 @@ __global__ __launch_bounds__(kRefitLeaves) void k_refit_leaves(RefitArgs A, uint
             sub.kind_flags = kind | (collapse ? kCollapsed : 0u);
             s_lo[lp] = lo; s_hi[lp] = hi; s_info[lp] = sub_pack(sub);
             node = p;
+            p = s_parent[lp];
         }
     }
     __syncthreads();
@@ -566,11 +603,14 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
         HIP_TRY(rocprim::exclusive_scan(st.temp.ptr, tb, (uint32_t *)st.flag_b.ptr, (uint32_t *)st.rank_b.ptr, 0u, n,
                                         rocprim::plus<uint32_t>(), stream));
     }
-    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, stream, in, n, order, mixed ? (const uint32_t *)st.rank_a.ptr : nullptr,
-                       mixed ? (const uint32_t *)st.rank_b.ptr : nullptr, (const float4 *)st.tri_shade.ptr, (float4 *)st.tri_pack.ptr, (float4 *)st.sphere_pack.ptr,
-                       (float4 *)st.quad_pack.ptr, (uint32_t *)st.sphere_ids.ptr, (uint32_t *)st.quad_ids.ptr,
-                       (uint32_t *)st.tri_ids.ptr, (uint32_t *)st.leaf_link.ptr, (uint32_t *)st.leaf_count.ptr);
-    HIP_TRY(hipGetLastError());
+    PackOut pout{(float4 *)st.tri_pack.ptr, (float4 *)st.sphere_pack.ptr, (float4 *)st.quad_pack.ptr, (uint32_t *)st.sphere_ids.ptr,
+                 (uint32_t *)st.quad_ids.ptr, (uint32_t *)st.tri_ids.ptr};
+    const uint32_t *rank_sphere = mixed ? (const uint32_t *)st.rank_a.ptr : nullptr, *rank_quad = mixed ? (const uint32_t *)st.rank_b.ptr : nullptr;
+    if (sah || n == 1) {      // the LBVH refit packs the records itself (k_refit_leaves)
+        hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, stream, in, n, order, rank_sphere, rank_quad, (const float4 *)st.tri_shade.ptr, pout,
+                           (uint32_t *)st.leaf_link.ptr, (uint32_t *)st.leaf_count.ptr);
+        HIP_TRY(hipGetLastError());
+    }
 
     if (n == 1) {
         hipLaunchKernelGGL(k_single_pair, dim3(1), dim3(64), 0, stream, order, (const float4 *)st.plo.ptr, (const float4 *)st.phi.ptr,
@@ -584,10 +624,9 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     }
     HIP_TRY(hipMemsetAsync(st.flag_a.ptr, 0, (size_t)n * 4, stream));
     RefitArgs ra;
-    ra.n = (int)n; ra.vals = vals; ra.plo = (const float4 *)st.plo.ptr; ra.phi = (const float4 *)st.phi.ptr;
+    ra.n = (int)n; ra.vals = vals; ra.in = in; ra.rank_sphere = rank_sphere; ra.rank_quad = rank_quad; ra.tri_shade = (const float4 *)st.tri_shade.ptr; ra.out = pout;
     ra.child_l = (const uint32_t *)st.child_l.ptr; ra.child_r = (const uint32_t *)st.child_r.ptr; ra.parent = (const uint32_t *)st.parent.ptr;
     ra.range_lo = (const uint32_t *)st.range_lo.ptr; ra.range_hi = (const uint32_t *)st.range_hi.ptr;
-    ra.leaf_link = (const uint32_t *)st.leaf_link.ptr; ra.leaf_count = (const uint32_t *)st.leaf_count.ptr;
     ra.nlo = (float4 *)st.nlo.ptr; ra.nhi = (float4 *)st.nhi.ptr; ra.ninfo = (float4 *)st.ninfo.ptr;
     ra.flags = (uint32_t *)st.flag_a.ptr; ra.pairs = (float4 *)st.pairs.ptr;
     ra.max_leaf = (flags & CRT_BVH_LEAF_COLLAPSE) ? (st.max_leaf < 1u ? 1u : st.max_leaf > 8u ? 8u : st.max_leaf) : 1u;

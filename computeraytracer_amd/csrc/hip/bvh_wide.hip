@@ -53,6 +53,7 @@ constexpr uint32_t kWideEmptyLink = kWideLeafTag | (3u << 29);
 
 struct WideChild { float lo[3], hi[3]; uint32_t link, count, budget; };
 
+
 __device__ __forceinline__ bool pad_leaf(uint32_t count) { return count != 0u && (count & 0x0FFFFFFFu) == 0u; }
 
 __device__ __forceinline__ void read_half(const float4 *half, WideChild &c) {
@@ -201,7 +202,7 @@ __device__ __forceinline__ void wide_emit(const float4 *pairs, const unsigned lo
             if (!pb) { S.set(n, b); n++; }
         }
         // node box, origin (rounded down to 15 mantissa bits) and per-axis grid step
-        float lo[3], hi[3], origin[3]; uint32_t ebits[3]; double scale[3];
+        float lo[3], hi[3], origin[3]; uint32_t ebits[3]; double scale[3], inv_scale[3];
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             lo[a] = S.c[0].lo[a]; hi[a] = S.c[0].hi[a];
@@ -216,6 +217,7 @@ __device__ __forceinline__ void wide_emit(const float4 *pairs, const unsigned lo
             e = e < -100 ? -100 : e;
             ebits[a] = (uint32_t)(e + 127);
             scale[a] = ldexp(1.0, e);
+            inv_scale[a] = ldexp(1.0, -e);      // the grid step is a power of two: dividing by it is this exact multiplication
         }
         // slot assignment: greedy maximum of sum_a (slot bit a ? +1 : -1) * (child centroid - node centre)_a.
         // slot_of: four bits per child; used / done: one bit per slot / child.
@@ -225,6 +227,32 @@ __device__ __forceinline__ void wide_emit(const float4 *pairs, const unsigned lo
 #pragma unroll
             for (int a = 0; a < 3; a++) dv[k][a] = (0.5f * S.c[k].lo[a] + 0.5f * S.c[k].hi[a]) - (0.5f * lo[a] + 0.5f * hi[a]);
         uint32_t slot_of = 0, slot_used = 0, child_done = 0;
+        if (!choice) {
+            // The per-frame LBVH rebuild (no table): children in order of decreasing |d|_1 (the score of a child's ideal slot, so the order in which the greedy rule
+            // below serves children whose ideal slot is still free); each takes its best free slot.  An eighth of the
+            // evaluations of the full greedy rule; on the headline scene it costs 0.14 % more node visits, so static (SAH +
+            // table) builds keep the full rule.
+            float l1[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) l1[k] = (fabsf(dv[k][0]) + fabsf(dv[k][1])) + fabsf(dv[k][2]);
+            for (int it = 0; it < n; it++) {
+                float top = -1.0f; int bk = -1;
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (k < n && !((child_done >> k) & 1u) && l1[k] > top) { top = l1[k]; bk = k; }
+                if (bk < 0) bk = __builtin_ctz(~child_done & ((1u << n) - 1u));      // only NaNs left
+                float d0 = dv[0][0], d1 = dv[0][1], d2 = dv[0][2];
+#pragma unroll
+                for (int k = 1; k < 8; k++) { d0 = k == bk ? dv[k][0] : d0; d1 = k == bk ? dv[k][1] : d1; d2 = k == bk ? dv[k][2] : d2; }
+                float best = -3.402823466e38f; int bs = -1;
+#pragma unroll
+                for (int sl = 0; sl < 8; sl++) {
+                    const float v = ((sl & 1) ? d0 : -d0) + ((sl & 2) ? d1 : -d1) + ((sl & 4) ? d2 : -d2);
+                    if (!((slot_used >> sl) & 1u) && v > best) { best = v; bs = sl; }
+                }
+                if (bs < 0) bs = __builtin_ctz(~slot_used & 0xFFu);
+                slot_of |= (uint32_t)bs << (4 * bk); child_done |= 1u << bk; slot_used |= 1u << bs;
+            }
+        } else
         for (int it = 0; it < n; it++) {
             float best = -3.402823466e38f; int bk = -1, bs = -1;
 #pragma unroll
@@ -263,8 +291,8 @@ __device__ __forceinline__ void wide_emit(const float4 *pairs, const unsigned lo
             const bool upper = sl >= 4u;
 #pragma unroll
             for (int a = 0; a < 3; a++) {
-                const double o = (double)origin[a], sc = scale[a];
-                double fl = floor(((double)S.c[k].lo[a] - o) / sc), fh = ceil(((double)S.c[k].hi[a] - o) / sc);
+                const double o = (double)origin[a], sc = scale[a], inv = inv_scale[a];
+                double fl = floor(((double)S.c[k].lo[a] - o) * inv), fh = ceil(((double)S.c[k].hi[a] - o) * inv);
                 fl = fl < 0.0 ? 0.0 : fl > 255.0 ? 255.0 : fl;
                 fh = fh < 0.0 ? 0.0 : fh > 255.0 ? 255.0 : fh;
                 while (fl > 0.0 && o + fl * sc > (double)S.c[k].lo[a]) fl -= 1.0;
