@@ -202,7 +202,9 @@ __device__ __forceinline__ void wide_emit(const float4 *pairs, const unsigned lo
             if (!pb) { S.set(n, b); n++; }
         }
         // node box, origin (rounded down to 15 mantissa bits) and per-axis grid step
-        float lo[3], hi[3], origin[3]; uint32_t ebits[3]; double scale[3], inv_scale[3];
+        // All in single precision (the double-precision version of this block and of the quantisation below ran at a half to
+        // a sixteenth of the FP32 rate and was most of this kernel's time); conservative by construction, see below.
+        float lo[3], hi[3], origin[3]; uint32_t ebits[3]; float inv_scale[3];
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             lo[a] = S.c[0].lo[a]; hi[a] = S.c[0].hi[a];
@@ -211,13 +213,18 @@ __device__ __forceinline__ void wide_emit(const float4 *pairs, const unsigned lo
             uint32_t b = __float_as_uint(lo[a]), t = b & 0xFFFFFE00u;
             if ((b & 0x80000000u) && t != b) t += 0x200u;          // negative: truncation moved it up, step one unit down
             origin[a] = __uint_as_float(t);
-            const double ext = (double)hi[a] - (double)origin[a];
+            // grid step 2^e with 255 * 2^e >= hi - origin.  ext carries a relative error of at most 2^-24 (one rounded
+            // subtraction), the division another 2^-24, so a quotient within 2^-20 of the next power of two takes that one.
+            const float ext = hi[a] - origin[a];
             int e = -100;
-            if (ext > 0.0) { int x; (void)frexp(ext / 255.0, &x); e = x; }      // 2^x >= ext / 255
-            e = e < -100 ? -100 : e;
+            if (ext > 0.0f) {
+                int x; const float m = frexpf(ext / 255.0f, &x);      // ext / 255 = m * 2^x, 0.5 <= m < 1
+                e = m > 0.999999f ? x + 1 : x;
+            }
+            if (!(ext <= 3.402823466e38f)) e = 122;                   // the subtraction overflowed (or a NaN box): 255 * 2^122 covers any finite extent
+            e = e < -100 ? -100 : e > 122 ? 122 : e;
             ebits[a] = (uint32_t)(e + 127);
-            scale[a] = ldexp(1.0, e);
-            inv_scale[a] = ldexp(1.0, -e);      // the grid step is a power of two: dividing by it is this exact multiplication
+            inv_scale[a] = __uint_as_float((uint32_t)(127 - e) << 23);      // 2^-e, exact (e in [-100, 122])
         }
         // slot assignment: greedy maximum of sum_a (slot bit a ? +1 : -1) * (child centroid - node centre)_a.
         // slot_of: four bits per child; used / done: one bit per slot / child.
@@ -291,12 +298,13 @@ __device__ __forceinline__ void wide_emit(const float4 *pairs, const unsigned lo
             const bool upper = sl >= 4u;
 #pragma unroll
             for (int a = 0; a < 3; a++) {
-                const double o = (double)origin[a], sc = scale[a], inv = inv_scale[a];
-                double fl = floor(((double)S.c[k].lo[a] - o) * inv), fh = ceil(((double)S.c[k].hi[a] - o) * inv);
-                fl = fl < 0.0 ? 0.0 : fl > 255.0 ? 255.0 : fl;
-                fh = fh < 0.0 ? 0.0 : fh > 255.0 ? 255.0 : fh;
-                while (fl > 0.0 && o + fl * sc > (double)S.c[k].lo[a]) fl -= 1.0;
-                while (fh < 255.0 && o + fh * sc < (double)S.c[k].hi[a]) fh += 1.0;
+                // x = (plane - origin) / 2^e in [0, 255]: the subtraction rounds once (relative 2^-24, i.e. at most 2^-16 in x),
+                // the scaling is exact; 2^-10 of slack towards the outside makes floor / ceil safe against that error, and
+                // costs a grid step only for planes within 2^-10 of a grid line.
+                const float xl = (S.c[k].lo[a] - origin[a]) * inv_scale[a], xh = (S.c[k].hi[a] - origin[a]) * inv_scale[a];
+                float fl = floorf(xl - 0.0009765625f), fh = ceilf(xh + 0.0009765625f);
+                fl = (fl >= 0.0f && fl <= 255.0f) ? fl : 0.0f;             // below the grid, or NaN / inf from an overflowed difference: the whole range
+                fh = (fh >= 0.0f && fh <= 255.0f) ? fh : 255.0f;
                 const uint32_t clr = ~(255u << sh), vl = (uint32_t)fl << sh, vh = (uint32_t)fh << sh;
                 if (upper) { q[a][1] = (q[a][1] & clr) | vl; q[3 + a][1] |= vh; }
                 else { q[a][0] = (q[a][0] & clr) | vl; q[3 + a][0] |= vh; }
