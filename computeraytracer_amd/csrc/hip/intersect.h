@@ -101,9 +101,12 @@ CRT_DEV int wrapi(float f, int n) { int i = (int)f % n; return i < 0 ? i + n : i
 
 // The texture a material samples: textures[0] as the shader does (compute.comp:387), or textures[textureIndex] with
 // CRT_EXT_TEXTURE_INDEX (crt_scene_upload / crt_extensions_set refuse an index past the array).
+// EXT = false: the kernels that run while no extension is set; they do not even test the flag (as a run-time branch with
+// per-lane texture sizes behind it, the test cost k_wf_shade 7 %).
+template <bool EXT>
 CRT_DEV const uint8_t *material_texture(const DeviceScene &sc, uint32_t texIndex, uint32_t &w, uint32_t &h) {
     w = sc.tex0_w; h = sc.tex0_h;
-    if (!(sc.ext & CRT_EXT_TEXTURE_INDEX)) return sc.tex0;
+    if (!EXT || !(sc.ext & CRT_EXT_TEXTURE_INDEX)) return sc.tex0;
     const uint4 e = sc.tex_table[texIndex];
     w = e.y; h = e.z;
     return sc.tex0 + 4 * (size_t)e.x;
@@ -135,7 +138,7 @@ CRT_DEV bool tri_alpha_pass(const DeviceScene &sc, uint32_t id, float beta, floa
     const float u = (alpha * c.z + beta * c.w) + gamma * e.x;
     const float v = (alpha * e.y + beta * e.z) + gamma * e.w;
     uint32_t w, h;
-    const uint8_t *tex = material_texture(sc, texIndex, w, h);
+    const uint8_t *tex = material_texture<true>(sc, texIndex, w, h);
     return !(texture_alpha(tex, w, h, u, v) < 0.5f);
 }
 
@@ -154,9 +157,9 @@ CRT_DEV bool slab(float4 lo, float4 hi, V3 idir, V3 noid, float tfar, float &tn)
     return tn <= tf;
 }
 
-// ALPHA: compiled only into the kernels that run when CRT_EXT_ALPHA_TEST is set (as a run-time branch it cost the
-// headline k_wf_extend 18 spilled VGPRs).
-template <bool COUNT, bool ALPHA>
+// EXT: compiled only into the kernels that run while some extension is set (as a run-time branch in the one kernel the
+// alpha test cost the headline k_wf_extend 18 spilled VGPRs).
+template <bool COUNT, bool EXT>
 CRT_DEV void test_leaf(const DeviceScene &sc, V3 o, V3 d, uint32_t first, uint32_t count_kind, float &best_t, uint32_t &best_id, Counts &cnt) {
     uint32_t kind = count_kind >> 28, n = count_kind & 0x0FFFFFFFu;
     if (COUNT) cnt.prims += n;
@@ -167,7 +170,7 @@ CRT_DEV void test_leaf(const DeviceScene &sc, V3 o, V3 d, uint32_t first, uint32
             float t, beta, gamma, invDet;
             if (tri_t(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, beta, gamma, invDet)) {
                 uint32_t id = f2u(c.y);
-                if (accept_hit(t, id, best_t, best_id) && (!ALPHA || tri_alpha_pass(sc, id, beta, gamma, invDet))) { best_t = t; best_id = id; }
+                if (accept_hit(t, id, best_t, best_id) && (!EXT || !(sc.ext & CRT_EXT_ALPHA_TEST) || tri_alpha_pass(sc, id, beta, gamma, invDet))) { best_t = t; best_id = id; }
             }
         }
     } else if (kind == CRT_ID_KIND_SPHERE) {
@@ -190,7 +193,7 @@ CRT_DEV void test_leaf(const DeviceScene &sc, V3 o, V3 d, uint32_t first, uint32
 }
 
 // R6: closest hit.  `stack` points at this lane's column of the block's LDS stack (stride = blockDim).
-template <bool COUNT, bool ALPHA = false>
+template <bool COUNT, bool EXT = false>
 CRT_DEV void closest_hit(const DeviceScene &sc, V3 o, V3 d, uint32_t *stack, uint32_t stack_stride,
                          float &best_t, uint32_t &best_id, Counts &cnt) {
     best_t = kInf; best_id = kIdMiss;
@@ -212,8 +215,8 @@ CRT_DEV void closest_hit(const DeviceScene &sc, V3 o, V3 d, uint32_t *stack, uin
         bool h0 = slab(lo0, hi0, idir, noid, tfar, tn0);
         bool h1 = slab(lo1, hi1, idir, noid, tfar, tn1);
         uint32_t c0 = f2u(hi0.w), c1 = f2u(hi1.w);
-        if (h0 && c0 != 0) { test_leaf<COUNT, ALPHA>(sc, o, d, f2u(lo0.w), c0, best_t, best_id, cnt); h0 = false; }
-        if (h1 && c1 != 0) { test_leaf<COUNT, ALPHA>(sc, o, d, f2u(lo1.w), c1, best_t, best_id, cnt); h1 = false; }
+        if (h0 && c0 != 0) { test_leaf<COUNT, EXT>(sc, o, d, f2u(lo0.w), c0, best_t, best_id, cnt); h0 = false; }
+        if (h1 && c1 != 0) { test_leaf<COUNT, EXT>(sc, o, d, f2u(lo1.w), c1, best_t, best_id, cnt); h1 = false; }
         tfar = best_t * 1.000004f;       // relative pad (2^-18) on the far bound
         uint32_t l0 = f2u(lo0.w), l1 = f2u(lo1.w);
         if (h0 && h1) {
@@ -293,11 +296,11 @@ CRT_DEV bool trav_inner(const DeviceScene &sc, Traversal &tr, uint32_t *stack, u
 }
 
 // Leaf phase: test the primitives of the leaf entry in tr.cur, then pop.
-template <bool COUNT, bool ALPHA = false>
+template <bool COUNT, bool EXT = false>
 CRT_DEV bool trav_leaf(const DeviceScene &sc, Traversal &tr, const uint32_t *stack, uint32_t stack_stride, const uint32_t *spill, int lds_depth, Counts &cnt) {
     const uint32_t e = tr.cur;
     const uint32_t kind = (e >> 29) & 3u, n = ((e >> 26) & 7u) + 1u, first = e & (kMaxLeafLink - 1u);
-    test_leaf<COUNT, ALPHA>(sc, tr.o, tr.d, first, (kind << 28) | n, tr.best_t, tr.best_id, cnt);
+    test_leaf<COUNT, EXT>(sc, tr.o, tr.d, first, (kind << 28) | n, tr.best_t, tr.best_id, cnt);
     tr.tfar = tr.best_t * 1.000004f;       // relative pad (2^-18) on the far bound
     return trav_pop(tr, stack, stack_stride, spill, lds_depth);
 }

@@ -151,12 +151,12 @@ CRT_DEV bool wide_inner(const float4 *nodes, const uint8_t *order, WideTrav &tr,
 }
 
 // Leaf step: tr.cur is a tagged leaf entry.
-template <bool COUNT, bool SPILL, bool ALPHA = false>
+template <bool COUNT, bool SPILL, bool EXT = false>
 CRT_DEV bool wide_leaf(const DeviceScene &sc, const uint8_t *order, WideTrav &tr, const uint2 *stack, uint32_t stack_stride, const uint2 *spill, int lds_depth, Counts &cnt) {
     const uint32_t e = tr.cur;
     const uint32_t kind = (e >> 29) & 3u, n = ((e >> 26) & 7u) + 1u, first = e & (kMaxLeafLink - 1u);
     if (kind != 3u) {                                   // 3 = empty slot (a box test can only reach it through rounding)
-        test_leaf<COUNT, ALPHA>(sc, tr.o, tr.d, first, (kind << 28) | n, tr.best_t, tr.best_id, cnt);
+        test_leaf<COUNT, EXT>(sc, tr.o, tr.d, first, (kind << 28) | n, tr.best_t, tr.best_id, cnt);
         tr.tfar = tr.best_t * 1.000004f;                // relative pad (2^-18) on the far bound
     }
     return wide_advance<SPILL>(sc.wide, order, tr, stack, stack_stride, spill, lds_depth);

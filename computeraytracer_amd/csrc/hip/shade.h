@@ -63,7 +63,7 @@ CRT_DEV bool should_refract(V3 incoming, V3 normal, float ior, float ratio, Rng<
 
 // One bounce of ray_color's loop body after a hit (compute.comp:451-455): emit + scatter + throughput
 // update.  Returns false when the path ends here; `result` then holds its radiance.
-template <int M>
+template <int M, bool EXT>
 CRT_DEV bool shade_hit(const DeviceScene &sc, V3 &o, V3 &d, float t, uint32_t id, Rng<M> &rng,
                        V3 &color, V3 &emitted, V3 &result) {
     HitRecord rec;
@@ -83,7 +83,7 @@ CRT_DEV bool shade_hit(const DeviceScene &sc, V3 &o, V3 &d, float t, uint32_t id
         if (texIndex != CRT_BAD_INDEX && sc.n_textures > 0) {
             resolve_uv(sc, o, d, id, rec);
             uint32_t tw, th;
-            const uint8_t *tex = material_texture(sc, texIndex, tw, th);      // always textures[0] (sic, :387) unless CRT_EXT_TEXTURE_INDEX
+            const uint8_t *tex = material_texture<EXT>(sc, texIndex, tw, th);      // always textures[0] (sic, :387) unless CRT_EXT_TEXTURE_INDEX
             attenuation = sample_texture(tex, tw, th, rec.u, rec.v);
         }
         o = rec.position; d = normalize3(dir);

@@ -82,7 +82,7 @@ __device__ __forceinline__ bool tile_pixel(const Frame &f, uint32_t tile, uint32
     return x < f.grid_w && y < f.grid_h;
 }
 
-template <int RNGM, bool COUNT, bool ALPHA = false>
+template <int RNGM, bool COUNT, bool EXT = false>
 __global__ __launch_bounds__(256) void k_megakernel(DeviceScene sc, Frame f, float4 *accum, uint32_t *hit_ids, DeviceStats *stats) {
     __shared__ uint32_t s_stack[kLdsStack * 256];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -108,12 +108,12 @@ __global__ __launch_bounds__(256) void k_megakernel(DeviceScene sc, Frame f, flo
         if (outline) pass = mk3(1.0f, 1.0f, 1.0f);
         for (uint32_t depth = 0; depth < f.max_bounces && !outline; depth++) {
             float t; uint32_t id; Counts cnt = {0, 0};
-            closest_hit<COUNT, ALPHA>(sc, o, d, s_stack + threadIdx.x, 256, t, id, cnt);
+            closest_hit<COUNT, EXT>(sc, o, d, s_stack + threadIdx.x, 256, t, id, cnt);
             rays++;
             if (COUNT) { nodes += cnt.nodes; prims += cnt.prims; }
             if (depth == 0) primary = id;
             if (id == kIdMiss) { pass = shade_miss(f.p, d, color); break; }
-            if (!shade_hit(sc, o, d, t, id, rng, color, emitted, pass)) break;
+            if (!shade_hit<RNGM, EXT>(sc, o, d, t, id, rng, color, emitted, pass)) break;
         }
         pass = pass * (1.0f / 1.0f);
         V3 cum = accumulate(mk3(cum4.x, cum4.y, cum4.z), pass, cam.iteration);
@@ -139,8 +139,8 @@ bool launch_megakernel(hipStream_t stream, const DeviceSceneHost &sch, const Fra
     if (f.n_tiles == 0) return true;
     dim3 grid((f.n_tiles + 3) / 4), block(256);
     float4 *acc = (float4 *)accum;
-    // (rng, instrumented, alpha test): the alpha-tested variants exist only as separate kernels (intersect.h test_leaf)
-    const int variant = (fs.rng_mode == CRT_RNG_REF ? 0 : 4) | (fs.instrumented ? 2 : 0) | ((sc.ext & CRT_EXT_ALPHA_TEST) ? 1 : 0);
+    // (rng, instrumented, extensions): the extensions' code exists only in separate kernels (intersect.h test_leaf)
+    const int variant = (fs.rng_mode == CRT_RNG_REF ? 0 : 4) | (fs.instrumented ? 2 : 0) | (sc.ext ? 1 : 0);
     switch (variant) {
 #define CRT_MEGA(V, R, C, A) case V: hipLaunchKernelGGL((k_megakernel<R, C, A>), grid, block, 0, stream, sc, f, acc, hit_ids, stats); break;
         CRT_MEGA(0, 0, false, false) CRT_MEGA(1, 0, false, true) CRT_MEGA(2, 0, true, false) CRT_MEGA(3, 0, true, true)
@@ -277,7 +277,7 @@ template <bool SPILL> struct LaneTrav<false, SPILL> {          // sibling-pair B
     CRT_DEV void begin(V3 o, V3 d) { trav_begin(tr, o, d); }
     CRT_DEV bool at_leaf() const { return (tr.cur & kLeafTag) != 0; }
     template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, const uint8_t *, Entry *stack, Entry *spill, int depth, Counts &c) { return trav_inner<COUNT>(sc, tr, stack, 256, spill, depth, c); }
-    template <bool COUNT, bool ALPHA> CRT_DEV bool leaf(const DeviceScene &sc, const uint8_t *, Entry *stack, Entry *spill, int depth, Counts &c) { return trav_leaf<COUNT, ALPHA>(sc, tr, stack, 256, spill, depth, c); }
+    template <bool COUNT, bool EXT> CRT_DEV bool leaf(const DeviceScene &sc, const uint8_t *, Entry *stack, Entry *spill, int depth, Counts &c) { return trav_leaf<COUNT, EXT>(sc, tr, stack, 256, spill, depth, c); }
 };
 template <bool SPILL> struct LaneTrav<true, SPILL> {           // 8-wide quantised BVH (intersect_wide.h)
     using Entry = uint2;
@@ -286,7 +286,7 @@ template <bool SPILL> struct LaneTrav<true, SPILL> {           // 8-wide quantis
     CRT_DEV void begin(V3 o, V3 d) { wide_begin(tr, o, d); }
     CRT_DEV bool at_leaf() const { return (tr.cur & kLeafTag) != 0; }
     template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, const uint8_t *order, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_inner<COUNT, SPILL>(sc.wide, order, tr, stack, 256, spill, depth, c); }
-    template <bool COUNT, bool ALPHA> CRT_DEV bool leaf(const DeviceScene &sc, const uint8_t *order, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_leaf<COUNT, SPILL, ALPHA>(sc, order, tr, stack, 256, spill, depth, c); }
+    template <bool COUNT, bool EXT> CRT_DEV bool leaf(const DeviceScene &sc, const uint8_t *order, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_leaf<COUNT, SPILL, EXT>(sc, order, tr, stack, 256, spill, depth, c); }
 };
 static_assert(kLdsStack * 4 == kWideLds * 8, "both stack layouts use the same LDS block");
 
@@ -295,9 +295,9 @@ static_assert(kLdsStack * 4 == kWideLds * 8, "both stack layouts use the same LD
 #endif
 // QUERY (crt_rays_query): 0 = path segments; 1 = caller's rays, closest hit in (t_near, t_max] (t_max rides in ray_o.w);
 // 2 = same interval, any hit: a lane stops at the first primitive it finds.
-// ALPHA: the CRT_EXT_ALPHA_TEST variant of the triangle test (always with SPILL: the extension's kernels are not the
-// headline path and one stack layout keeps their number down).
-template <bool COUNT, bool WIDE, bool SPILL, int QUERY = 0, bool ALPHA = false>
+// EXT: the variant that looks at the CRT_EXT_* flags (always with SPILL: the extensions' kernels are not the headline
+// path and one stack layout keeps their number down).
+template <bool COUNT, bool WIDE, bool SPILL, int QUERY = 0, bool EXT = false>
 __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene sc, WfQueues q, uint32_t bounce, unsigned long long dead, DeviceStats *stats) {
     __shared__ uint2 s_stack[kWideLds * 256];
     __shared__ uint8_t s_order[WIDE ? kWideOrderBytes : 4];
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
         bool more = true;
         if (n_leaf >= q.leaf_lanes || !any_inner) {
             if (COUNT) { c_leaf++; c_leaf_lanes += n_leaf; }
-            if (at_leaf) more = lt.template leaf<COUNT, ALPHA>(sc, s_order, stack, spill, lds_depth, cnt);
+            if (at_leaf) more = lt.template leaf<COUNT, EXT>(sc, s_order, stack, spill, lds_depth, cnt);
         } else {
             if (COUNT) { c_inner++; c_inner_lanes += (uint32_t)__popcll(__ballot(busy && !at_leaf)); }
             if (busy && !at_leaf) more = lt.template inner<COUNT>(sc, s_order, stack, spill, lds_depth, cnt);
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
 #ifndef CRT_SHADE_WAVES
 #define CRT_SHADE_WAVES 6
 #endif
-template <int RNGM>
+template <int RNGM, bool EXT = false>
 __global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene sc, Frame f, WfQueues q, uint32_t bounce, float4 *pass_buf, uint32_t pass_stride, uint32_t *hit_ids) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t in = bounce & 1, out = in ^ 1;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene s
                 if (bounce == 0 && it + 1 == f.n_batch) hit_ids[pix] = id;
                 V3 pass = mk3(0.0f, 0.0f, 0.0f);
                 if (id == kIdMiss) pass = shade_miss(f.p, d, color);
-                else alive = shade_hit(sc, o, d, t, id, rng, color, emitted, pass);
+                else alive = shade_hit<RNGM, EXT>(sc, o, d, t, id, rng, color, emitted, pass);
                 if (alive && last) { alive = false; pass = mk3(0.0f, 0.0f, 0.0f); }     // "Kill ray after MAX_BOUNCES", compute.comp:457
                 if (!alive) {                                                            // main(), :470-473; k_wf_accumulate adds it in
                     pass = pass * (1.0f / 1.0f);
@@ -519,8 +519,8 @@ static bool ensure_dev(DeviceBuffer &b, size_t bytes, std::string &err) {
     return true;
 }
 
-// One place that picks the k_wf_extend instantiation.  wide/spill as launch_wavefront decides them; alpha (the
-// CRT_EXT_ALPHA_TEST kernels) always takes the SPILL layout; queries are never instrumented.
+// One place that picks the k_wf_extend instantiation.  wide/spill as launch_wavefront decides them; alpha (some CRT_EXT_*
+// flag is set: the EXT kernels) always takes the SPILL layout; queries are never instrumented.
 template <int QUERY>
 static void launch_extend(bool count, bool wide, bool spill, bool alpha, dim3 grid, hipStream_t stream, const DeviceScene &sc,
                           const WfQueues &q, uint32_t bounce, unsigned long long dead, DeviceStats *stats) {
@@ -614,11 +614,14 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
         }
         q.lds_depth = fs.small_stack ? 1u : (sc.wide ? (uint32_t)kWideLds : (uint32_t)kLdsStack);
         // wide trees of at most lds_depth + 1 levels never overflow the LDS stack (at most levels - 1 groups wait on it)
-        launch_extend<0>(fs.instrumented, sc.wide != nullptr, !(sc.wide && sch.wide_levels <= q.lds_depth + 1u), (sc.ext & CRT_EXT_ALPHA_TEST) != 0,
+        launch_extend<0>(fs.instrumented, sc.wide != nullptr, !(sc.wide && sch.wide_levels <= q.lds_depth + 1u), sc.ext != 0,
                          pgrid, stream, sc, q, b, dead_b, stats);
         if (wf.time_kernels) HIP_TRY(hipEventRecord(wf.ev[wf.ev_used + 1], stream));
-        if (pcg) hipLaunchKernelGGL((k_wf_shade<1>), sgrid, block, 0, stream, sc, f, q, b, (float4 *)wf.pass.ptr, accum_pixels, hit_ids);
-        else hipLaunchKernelGGL((k_wf_shade<0>), sgrid, block, 0, stream, sc, f, q, b, (float4 *)wf.pass.ptr, accum_pixels, hit_ids);
+        if (sc.ext) {
+            if (pcg) hipLaunchKernelGGL((k_wf_shade<1, true>), sgrid, block, 0, stream, sc, f, q, b, (float4 *)wf.pass.ptr, accum_pixels, hit_ids);
+            else hipLaunchKernelGGL((k_wf_shade<0, true>), sgrid, block, 0, stream, sc, f, q, b, (float4 *)wf.pass.ptr, accum_pixels, hit_ids);
+        } else if (pcg) hipLaunchKernelGGL((k_wf_shade<1, false>), sgrid, block, 0, stream, sc, f, q, b, (float4 *)wf.pass.ptr, accum_pixels, hit_ids);
+        else hipLaunchKernelGGL((k_wf_shade<0, false>), sgrid, block, 0, stream, sc, f, q, b, (float4 *)wf.pass.ptr, accum_pixels, hit_ids);
         if (wf.time_kernels) { HIP_TRY(hipEventRecord(wf.ev[wf.ev_used + 2], stream)); wf.ev_used += 3; }
     }
     hipLaunchKernelGGL(k_wf_accumulate, acc_grid, block, 0, stream, f, acc, (const float4 *)wf.pass.ptr, accum_pixels);
@@ -682,7 +685,7 @@ bool launch_ray_query(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     hipLaunchKernelGGL(k_query_init, dim3(1), dim3(256), 0, stream, q, n_rays);
     hipLaunchKernelGGL(k_query_pack, dim3((n_rays + 255) / 256), block, 0, stream, q, (const crt_ray *)wf.query_rays.ptr, n_rays);
     const bool any = mode == CRT_QUERY_ANY;
-    const bool spill = !(sc.wide && sch.wide_levels <= q.lds_depth + 1u), alpha = (sc.ext & CRT_EXT_ALPHA_TEST) != 0;
+    const bool spill = !(sc.wide && sch.wide_levels <= q.lds_depth + 1u), alpha = sc.ext != 0;
     if (any) launch_extend<2>(false, sc.wide != nullptr, spill, alpha, pgrid, stream, sc, q, 0u, 0ull, stats);
     else launch_extend<1>(false, sc.wide != nullptr, spill, alpha, pgrid, stream, sc, q, 0u, 0ull, stats);
     HIP_TRY(hipGetLastError());
@@ -756,7 +759,7 @@ bool launch_ray_query_noalloc(hipStream_t stream, int device, const DeviceSceneH
     hipLaunchKernelGGL(k_query_init, dim3(1), dim3(256), 0, stream, q, n_rays);
     hipLaunchKernelGGL(k_query_pack, dim3((n_rays + 255) / 256), block, 0, stream, q, rays_dev, n_rays);
     const bool any = mode == CRT_QUERY_ANY;
-    const bool spill = !(sc.wide && sch.wide_levels <= q.lds_depth + 1u), alpha = (sc.ext & CRT_EXT_ALPHA_TEST) != 0;
+    const bool spill = !(sc.wide && sch.wide_levels <= q.lds_depth + 1u), alpha = sc.ext != 0;
     if (any) launch_extend<2>(false, sc.wide != nullptr, spill, alpha, pgrid, stream, sc, q, 0u, 0ull, stats);
     else launch_extend<1>(false, sc.wide != nullptr, spill, alpha, pgrid, stream, sc, q, 0u, 0ull, stats);
     HIP_TRY(hipGetLastError());
