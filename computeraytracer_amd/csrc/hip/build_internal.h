@@ -61,7 +61,7 @@ struct DeviceSceneHost {       // host-side mirror of DeviceScene (kept POD so c
     const void *wide; uint32_t n_wide, wide_levels;     // 8-wide nodes (null: the wavefront tracer walks the pair BVH)
     const void *tri_pack, *sphere_pack, *quad_pack, *tri_shade;
     const uint32_t *sphere_ids, *quad_ids;
-    const crt_sphere *spheres; const crt_quad *quads; const crt_tri *tris;
+    const crt_sphere *spheres; const crt_quad *quads; const crt_tri *tris; uint32_t n_tris;
     const crt_material *materials;
     const uint8_t *tex0; uint32_t tex0_w, tex0_h, n_textures;
     const uint4 *tex_table; uint32_t ext;

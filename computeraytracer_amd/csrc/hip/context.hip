@@ -26,7 +26,7 @@ struct crt_context {
     crt_config cfg{};
     bool configured = false, have_scene = false, have_bvh = false;
     // scene (reference layouts, input order)
-    DeviceBuffer spheres, quads, tris, tris_rest, materials, tex0, tex_table, dbg_boxes;      // tex0: every texture, textures[0] first
+    DeviceBuffer spheres, quads, tris, tris_rest, materials, tex0, tex_table, dbg_boxes, dbg_scan;      // tex0: every texture, textures[0] first; dbg_scan: two flag words of k_tri_material_scan
     uint32_t n_dbg_boxes = 0;
     uint32_t n_spheres = 0, n_quads = 0, n_tris = 0, n_materials = 0, n_textures = 0, tex0_w = 0, tex0_h = 0;
     uint32_t ext = 0;               // CRT_EXT_* (crt_extensions_set)
@@ -48,6 +48,13 @@ namespace {
 int fail(crt_context *ctx, int code, const std::string &msg) { if (ctx) ctx->error = msg; return code; }
 
 #define CTX_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(ctx, CRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+// out[0] = some materialIndex in a range of device-resident triangles is past the material array (the kernels index it
+// unchecked).
+__global__ void k_tri_material_scan(const crt_tri *tris, uint32_t first, uint32_t count, uint32_t n_materials, uint32_t *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count && tris[first + i].materialIndex >= n_materials) out[0] = 1u;
+}
 
 int bind(crt_context *ctx) {
     if (!ctx) return CRT_ERR_INVALID;
@@ -86,7 +93,7 @@ DeviceSceneHost scene_view(const crt_context *ctx) {
     s.tri_pack = ctx->build.tri_pack.ptr; s.sphere_pack = ctx->build.sphere_pack.ptr; s.quad_pack = ctx->build.quad_pack.ptr;
     s.tri_shade = ctx->build.tri_shade.ptr;
     s.sphere_ids = (const uint32_t *)ctx->build.sphere_ids.ptr; s.quad_ids = (const uint32_t *)ctx->build.quad_ids.ptr;
-    s.spheres = (const crt_sphere *)ctx->spheres.ptr; s.quads = (const crt_quad *)ctx->quads.ptr; s.tris = (const crt_tri *)ctx->tris.ptr;
+    s.spheres = (const crt_sphere *)ctx->spheres.ptr; s.quads = (const crt_quad *)ctx->quads.ptr; s.tris = (const crt_tri *)ctx->tris.ptr; s.n_tris = ctx->n_tris;
     s.materials = (const crt_material *)ctx->materials.ptr;
     s.tex0 = (const uint8_t *)ctx->tex0.ptr; s.tex0_w = ctx->tex0_w; s.tex0_h = ctx->tex0_h; s.n_textures = ctx->n_textures;
     s.tex_table = (const uint4 *)ctx->tex_table.ptr; s.ext = ctx->ext;
@@ -214,7 +221,7 @@ void crt_destroy(crt_context *ctx) {
     if (!ctx) return;
     if (hipSetDevice(ctx->device) == hipSuccess) {
         hipError_t e = hipStreamSynchronize(ctx->stream); (void)e;
-        DeviceBuffer *all[] = {&ctx->spheres, &ctx->quads, &ctx->tris, &ctx->tris_rest, &ctx->materials, &ctx->tex0, &ctx->tex_table, &ctx->dbg_boxes, &ctx->accum, &ctx->hit_ids, &ctx->stats};
+        DeviceBuffer *all[] = {&ctx->spheres, &ctx->quads, &ctx->tris, &ctx->tris_rest, &ctx->materials, &ctx->tex0, &ctx->tex_table, &ctx->dbg_boxes, &ctx->dbg_scan, &ctx->accum, &ctx->hit_ids, &ctx->stats};
         for (DeviceBuffer *b : all) release(*b);
         free_build_state(ctx->build);
         free_wavefront(ctx->wf);
@@ -360,6 +367,22 @@ int crt_tris_update(crt_context *ctx, const crt_tri *tris, uint32_t first, uint3
     // crt_tris_animate displaces the NEW vertices instead of silently restoring the old ones
     if (ctx->animated) CTX_HIP(hipMemcpy((crt_tri *)ctx->tris_rest.ptr + first, tris, (size_t)count * sizeof(crt_tri), hipMemcpyDefault));
     ctx->have_bvh = false;
+    // The new triangles may live in device memory, so the device checks them: material indices in range (the kernels
+    // index the material array unchecked).
+    if (count) {
+        uint32_t *flags = (uint32_t *)ctx->dbg_scan.ptr;
+        if (!flags) { if ((rc = alloc(ctx, ctx->dbg_scan, 256))) return rc; flags = (uint32_t *)ctx->dbg_scan.ptr; }
+        CTX_HIP(hipMemsetAsync(flags, 0, 8, ctx->stream));
+        hipLaunchKernelGGL(k_tri_material_scan, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, (const crt_tri *)ctx->tris.ptr, first, count,
+                           ctx->n_materials, flags);
+        uint32_t host_flags[2] = {0, 0};
+        CTX_HIP(hipMemcpyAsync(host_flags, flags, 8, hipMemcpyDeviceToHost, ctx->stream));
+        CTX_HIP(hipStreamSynchronize(ctx->stream));
+        if (host_flags[0]) {
+            ctx->have_scene = false;
+            return fail(ctx, CRT_ERR_INVALID, "crt_tris_update: triangle material index out of range (the scene is no longer usable: upload it again)");
+        }
+    }
     return CRT_OK;
 }
 

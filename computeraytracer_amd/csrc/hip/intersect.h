@@ -26,6 +26,7 @@ struct DeviceScene {
     const crt_sphere *spheres;  // as uploaded (input order): shading data
     const crt_quad *quads;
     const crt_tri *tris;
+    uint32_t n_tris;            // 0: tri_shade holds no record
     const crt_material *materials;
     const uint8_t *tex0;        // textures[0], RGBA8 rows top-down (the shader only ever samples index 0, compute.comp:387);
                                 // the scene's other textures follow it in the same allocation (tex_table)
@@ -329,14 +330,19 @@ CRT_DEV void sphere_uv(V3 outward, float &u, float &v) {   // compute.comp:247-2
     v = theta / kPi;
 }
 
+// The 64-byte shading record of a triangle (DeviceScene::tri_shade) in registers.  k_wf_shade fetches it with the four
+// lanes of a quad working together (tri_rec_quad_fetch, PRE = true); for the other callers the record is read here.
+struct TriRec { float4 a, b, c, e; };
+
 // Position, face normal and material of the winning primitive.
-CRT_DEV void resolve_hit(const DeviceScene &sc, V3 o, V3 d, float t, uint32_t id, HitRecord &rec) {
+template <bool PRE = false>
+CRT_DEV void resolve_hit(const DeviceScene &sc, V3 o, V3 d, float t, uint32_t id, HitRecord &rec, const TriRec &pre = TriRec()) {
     uint32_t kind = id >> 30, idx = id & 0x3FFFFFFFu;
     rec.u = 0.0f; rec.v = 0.0f;
     rec.position = o + t * d;
     if (kind == CRT_ID_KIND_TRI) {                       // compute.comp:303-307
         const float4 *p = sc.tri_shade + 4 * (size_t)idx;
-        const float4 a = p[0], b = p[1], c = p[2];
+        const float4 a = PRE ? pre.a : p[0], b = PRE ? pre.b : p[1], c = PRE ? pre.c : p[2];
         const V3 e10 = mk3(a.w, b.x, b.y), e20 = mk3(b.z, b.w, c.x);      // v1 - v0, v2 - v0 (bvh_build.hip: write_tri_shade)
         set_face_normal(d, cross3(e20, e10), rec);       // not normalised (sic)
         rec.materialIndex = f2u(c.y);
@@ -354,11 +360,12 @@ CRT_DEV void resolve_hit(const DeviceScene &sc, V3 o, V3 d, float t, uint32_t id
 
 // Texture coordinates of the hit; only evaluated for a textured material (the values are the ones the
 // shader computes at every hit and then ignores for untextured materials).
-CRT_DEV void resolve_uv(const DeviceScene &sc, V3 o, V3 d, uint32_t id, HitRecord &rec) {
+template <bool PRE = false>
+CRT_DEV void resolve_uv(const DeviceScene &sc, V3 o, V3 d, uint32_t id, HitRecord &rec, const TriRec &pre = TriRec()) {
     uint32_t kind = id >> 30, idx = id & 0x3FFFFFFFu;
     if (kind == CRT_ID_KIND_TRI) {                       // compute.comp:309-314
         const float4 *p = sc.tri_shade + 4 * (size_t)idx;
-        const float4 a = p[0], b = p[1], c = p[2], e = p[3];
+        const float4 a = PRE ? pre.a : p[0], b = PRE ? pre.b : p[1], c = PRE ? pre.c : p[2], e = PRE ? pre.e : p[3];
         const V3 v0 = mk3(a.x, a.y, a.z), e10 = mk3(a.w, b.x, b.y), e20 = mk3(b.z, b.w, c.x);
         float tt, beta, gamma, invDet;
         tri_t(o, d, v0, e10, e20, tt, beta, gamma, invDet);

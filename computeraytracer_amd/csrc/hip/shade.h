@@ -40,6 +40,40 @@ CRT_DEV V3 sample_texture(const uint8_t *tex, uint32_t w, uint32_t h, float u, f
     return top * (1.0f - fy) + bot * fy;
 }
 
+// The triangle records of a wave's 64 hits, fetched by quads: in round r the four lanes of a quad read the four 16-byte
+// quarters of the record that the quad's lane r wants, i.e. 64 contiguous bytes per quad and instruction, which the
+// address path serves as one request where four separate 16-byte loads per lane are 64 requests per instruction (these
+// loads were 45 % of k_wf_shade's address-path cycles, its busiest unit).  A 4 x 4 transpose inside the quad (two
+// rounds of DPP quad_perm + selects) then hands every lane the four quarters of its own record.  Call with all 64 lanes
+// active; `idx` must be a valid record for every lane (lanes without a triangle hit pass 0).
+CRT_DEV float4 quad_xchg(float4 v, bool xor2) {
+    float4 r;
+    if (xor2) {
+        r.x = u2f((uint32_t)__builtin_amdgcn_mov_dpp((int)f2u(v.x), 0x4E, 0xF, 0xF, true)); r.y = u2f((uint32_t)__builtin_amdgcn_mov_dpp((int)f2u(v.y), 0x4E, 0xF, 0xF, true));
+        r.z = u2f((uint32_t)__builtin_amdgcn_mov_dpp((int)f2u(v.z), 0x4E, 0xF, 0xF, true)); r.w = u2f((uint32_t)__builtin_amdgcn_mov_dpp((int)f2u(v.w), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    } else {
+        r.x = u2f((uint32_t)__builtin_amdgcn_mov_dpp((int)f2u(v.x), 0xB1, 0xF, 0xF, true)); r.y = u2f((uint32_t)__builtin_amdgcn_mov_dpp((int)f2u(v.y), 0xB1, 0xF, 0xF, true));
+        r.z = u2f((uint32_t)__builtin_amdgcn_mov_dpp((int)f2u(v.z), 0xB1, 0xF, 0xF, true)); r.w = u2f((uint32_t)__builtin_amdgcn_mov_dpp((int)f2u(v.w), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    }
+    return r;
+}
+CRT_DEV float4 sel4(bool p, float4 a, float4 b) { return make_float4(p ? a.x : b.x, p ? a.y : b.y, p ? a.z : b.z, p ? a.w : b.w); }
+CRT_DEV TriRec tri_rec_quad_fetch(const float4 *tri_shade, uint32_t idx, uint32_t lane) {
+    const uint32_t j = lane & 3u;
+    float4 R[4];
+    const uint32_t o0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)idx, 0x00, 0xF, 0xF, true), o1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)idx, 0x55, 0xF, 0xF, true);      // quad_perm [r,r,r,r]
+    const uint32_t o2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)idx, 0xAA, 0xF, 0xF, true), o3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)idx, 0xFF, 0xF, 0xF, true);
+    R[0] = tri_shade[4 * (size_t)o0 + j]; R[1] = tri_shade[4 * (size_t)o1 + j]; R[2] = tri_shade[4 * (size_t)o2 + j]; R[3] = tri_shade[4 * (size_t)o3 + j];
+    // transpose: afterwards R[p] of lane j = quarter p of the record of lane j
+    const bool b0 = (j & 1u) != 0u, b1 = (j & 2u) != 0u;
+    const float4 x0 = quad_xchg(R[1], false), x1 = quad_xchg(R[0], false), x2 = quad_xchg(R[3], false), x3 = quad_xchg(R[2], false);
+    const float4 T0 = sel4(b0, x0, R[0]), T1 = sel4(b0, R[1], x1), T2 = sel4(b0, x2, R[2]), T3 = sel4(b0, R[3], x3);
+    const float4 y0 = quad_xchg(T2, true), y1 = quad_xchg(T3, true), y2 = quad_xchg(T0, true), y3 = quad_xchg(T1, true);
+    TriRec out;
+    out.a = sel4(b1, y0, T0); out.b = sel4(b1, y1, T1); out.c = sel4(b1, T2, y2); out.e = sel4(b1, T3, y3);
+    return out;
+}
+
 CRT_DEV V3 reflect3(V3 I, V3 N) { return I - (2.0f * dot3(N, I)) * N; }           // GLSL reflect
 CRT_DEV V3 refract3(V3 I, V3 N, float eta) {                                     // GLSL refract
     float ni = dot3(N, I);
@@ -63,11 +97,11 @@ CRT_DEV bool should_refract(V3 incoming, V3 normal, float ior, float ratio, Rng<
 
 // One bounce of ray_color's loop body after a hit (compute.comp:451-455): emit + scatter + throughput
 // update.  Returns false when the path ends here; `result` then holds its radiance.
-template <int M, bool EXT>
+template <int M, bool EXT, bool PRE = false>
 CRT_DEV bool shade_hit(const DeviceScene &sc, V3 &o, V3 &d, float t, uint32_t id, Rng<M> &rng,
-                       V3 &color, V3 &emitted, V3 &result) {
+                       V3 &color, V3 &emitted, V3 &result, const TriRec &pre = TriRec()) {
     HitRecord rec;
-    resolve_hit(sc, o, d, t, id, rec);
+    resolve_hit<PRE>(sc, o, d, t, id, rec, pre);
     const float4 *mp = (const float4 *)(sc.materials + rec.materialIndex);
     float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
     V3 albedo = mk3(m0.x, m0.y, m0.z);
@@ -81,7 +115,7 @@ CRT_DEV bool shade_hit(const DeviceScene &sc, V3 &o, V3 &d, float t, uint32_t id
     if (type == CRT_MAT_LAMBERTIAN) {
         V3 dir = rec.normal + random_in_unit_sphere(rng);
         if (texIndex != CRT_BAD_INDEX && sc.n_textures > 0) {
-            resolve_uv(sc, o, d, id, rec);
+            resolve_uv<PRE>(sc, o, d, id, rec, pre);
             uint32_t tw, th;
             const uint8_t *tex = material_texture<EXT>(sc, texIndex, tw, th);      // always textures[0] (sic, :387) unless CRT_EXT_TEXTURE_INDEX
             attenuation = sample_texture(tex, tw, th, rec.u, rec.v);

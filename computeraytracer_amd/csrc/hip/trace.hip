@@ -39,7 +39,7 @@ static DeviceScene to_device_scene(const DeviceSceneHost &h) {
     d.tri_pack = (const float4 *)h.tri_pack; d.sphere_pack = (const float4 *)h.sphere_pack; d.quad_pack = (const float4 *)h.quad_pack;
     d.tri_shade = (const float4 *)h.tri_shade;
     d.sphere_ids = h.sphere_ids; d.quad_ids = h.quad_ids;
-    d.spheres = h.spheres; d.quads = h.quads; d.tris = h.tris; d.materials = h.materials;
+    d.spheres = h.spheres; d.quads = h.quads; d.tris = h.tris; d.n_tris = h.n_tris; d.materials = h.materials;
     d.tex0 = h.tex0; d.tex0_w = h.tex0_w; d.tex0_h = h.tex0_h; d.n_textures = h.n_textures;
     d.tex_table = h.tex_table; d.ext = h.ext;
     d.dbg_boxes = (const float4 *)h.dbg_boxes; d.n_dbg_boxes = h.n_dbg_boxes;
@@ -451,13 +451,18 @@ __global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene s
         V3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), color = mk3(0, 0, 0);
         uint32_t pix = kDeadPixel, it = 0;
         Rng<RNGM> rng;
-        if (i < n) {
-            const uint32_t slot = s * q.shard_cap + i;
-            float4 d4 = q.ray_d[in][slot];
+        // every lane of the wave takes part in the triangle-record fetch (shade.h tri_rec_quad_fetch), so the hit is read
+        // first and by all lanes; lanes without a live path or a triangle hit ask for record 0
+        const uint32_t slot = s * q.shard_cap + min(i, n - 1u);
+        const float4 d4 = q.ray_d[in][slot];
+        const uint2 h = q.hit[slot];
+        const bool live = i < n && f2u(d4.w) != kDeadPixel;
+        TriRec trec = {make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
+        if (sc.n_tris != 0u) trec = tri_rec_quad_fetch(sc.tri_shade, (live && (h.y >> 30) == CRT_ID_KIND_TRI) ? (h.y & 0x3FFFFFFFu) : 0u, lane);
+        if (live) {
             pix = f2u(d4.w);
-            if (pix != kDeadPixel) {
+            {
                 float4 o4 = q.ray_o[in][slot], c4 = q.thr[in][slot];
-                uint2 h = q.hit[slot];
                 o = mk3(o4.x, o4.y, o4.z); d = mk3(d4.x, d4.y, d4.z);
                 color = mk3(c4.x, c4.y, c4.z);
                 V3 emitted = mk3(0.0f, 0.0f, 0.0f);      // see the queue-entry comment
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene s
                 if (bounce == 0 && it + 1 == f.n_batch) hit_ids[pix] = id;
                 V3 pass = mk3(0.0f, 0.0f, 0.0f);
                 if (id == kIdMiss) pass = shade_miss(f.p, d, color);
-                else alive = shade_hit<RNGM, EXT>(sc, o, d, t, id, rng, color, emitted, pass);
+                else alive = shade_hit<RNGM, EXT, true>(sc, o, d, t, id, rng, color, emitted, pass, trec);
                 if (alive && last) { alive = false; pass = mk3(0.0f, 0.0f, 0.0f); }     // "Kill ray after MAX_BOUNCES", compute.comp:457
                 if (!alive) {                                                            // main(), :470-473; k_wf_accumulate adds it in
                     pass = pass * (1.0f / 1.0f);

@@ -78,7 +78,9 @@ int crt_bvh_build(crt_context *ctx, uint32_t flags, float *build_ms);
 
 /* Config 5 (per-frame rebuild): overwrite the triangle vertices in place from
  * device-resident or host memory, then call crt_bvh_build again.  No
- * counterpart in the reference (its BVHs are built once: vk_engine.cpp:748-934). */
+ * counterpart in the reference (its BVHs are built once: vk_engine.cpp:748-934).  The
+ * new triangles' material indices are checked on the device; one past the material
+ * array fails with CRT_ERR_INVALID and leaves the context without a scene (upload again). */
 int crt_tris_update(crt_context *ctx, const crt_tri *tris, uint32_t first, uint32_t count);
 /* Reads triangles [first, first + count) back as they are on the device now (after crt_tris_animate / crt_tris_update)
  * into host or device memory.  Synchronous.  Build-only diagnostic: the parity tests hand these triangles to the oracle. */

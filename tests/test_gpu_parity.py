@@ -732,6 +732,13 @@ def test_config5_animate_rebuild_and_update(ctx):
     check_frame(4, rest2, seeds[3])
     with pytest.raises(abi.CrtError, match="range"):
         ctx.tris_update(new, first=len(rest) - 10)
+    # a material index past the material array is refused (the kernels index that array unchecked) and costs the scene
+    bad = new[:3].copy()
+    bad["materialIndex"][1] = len(scene.materials)
+    with pytest.raises(abi.CrtError, match="material index out of range"):
+        ctx.tris_update(bad, first=10)
+    with pytest.raises(abi.CrtError, match="no scene"):
+        ctx.build(abi.BVH_WIDE)
 
 
 def _nested_scene(n, w, h):
