@@ -63,7 +63,7 @@ struct DeviceSceneHost {       // host-side mirror of DeviceScene (kept POD so c
     const uint32_t *sphere_ids, *quad_ids;
     const crt_sphere *spheres; const crt_quad *quads; const crt_tri *tris; uint32_t n_tris;
     const crt_material *materials;
-    const uint8_t *tex0; uint32_t tex0_w, tex0_h, n_textures;
+    const uint4 *tex0; uint32_t tex0_w, tex0_h, n_textures;      // bilinear footprints (intersect.h DeviceScene::tex0)
     const uint4 *tex_table; uint32_t ext;
     const void *dbg_boxes; uint32_t n_dbg_boxes;     // crt_debug_boxes_upload (R15)
 };

@@ -26,7 +26,7 @@ struct crt_context {
     crt_config cfg{};
     bool configured = false, have_scene = false, have_bvh = false;
     // scene (reference layouts, input order)
-    DeviceBuffer spheres, quads, tris, tris_rest, materials, tex0, tex_table, dbg_boxes, dbg_scan;      // tex0: every texture, textures[0] first; dbg_scan: two flag words of k_tri_material_scan
+    DeviceBuffer spheres, quads, tris, tris_rest, materials, tex0, tex_fp, tex_table, dbg_boxes, dbg_scan;      // tex0: every texture's RGBA8 texels, textures[0] first (staging during upload); tex_fp: their footprint form (k_tex_footprints), what the kernels sample; dbg_scan: two flag words of k_tri_material_scan
     uint32_t n_dbg_boxes = 0;
     uint32_t n_spheres = 0, n_quads = 0, n_tris = 0, n_materials = 0, n_textures = 0, tex0_w = 0, tex0_h = 0;
     uint32_t ext = 0;               // CRT_EXT_* (crt_extensions_set)
@@ -54,6 +54,21 @@ int fail(crt_context *ctx, int code, const std::string &msg) { if (ctx) ctx->err
 __global__ void k_tri_material_scan(const crt_tri *tris, uint32_t first, uint32_t count, uint32_t n_materials, uint32_t *out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count && tris[first + i].materialIndex >= n_materials) out[0] = 1u;
+}
+
+// Footprint form of the resident textures: entry (x, y) of a texture = its texels (x, y), (x+1, y), (x, y+1), (x+1, y+1)
+// with REPEAT wrap (the four a bilinear sample at (x, y) blends, vk_initializers.cpp:252-261), so a sample is one 16-byte
+// load.  table[t] = {first texel, width, height, 0}; one thread per texel of all textures.
+__global__ void k_tex_footprints(const uint32_t *texels, const uint4 *table, uint32_t n_textures, uint32_t n_texels, uint4 *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_texels) return;
+    uint32_t t = 0;
+    while (t + 1 < n_textures && table[t + 1].x <= i) t++;
+    const uint4 e = table[t];
+    const uint32_t local = i - e.x, y = local / e.y, x = local - y * e.y;
+    const uint32_t x1 = x + 1 == e.y ? 0u : x + 1, y1 = y + 1 == e.z ? 0u : y + 1;
+    const uint32_t *base = texels + e.x;
+    out[i] = make_uint4(base[(size_t)y * e.y + x], base[(size_t)y * e.y + x1], base[(size_t)y1 * e.y + x], base[(size_t)y1 * e.y + x1]);
 }
 
 int bind(crt_context *ctx) {
@@ -95,7 +110,7 @@ DeviceSceneHost scene_view(const crt_context *ctx) {
     s.sphere_ids = (const uint32_t *)ctx->build.sphere_ids.ptr; s.quad_ids = (const uint32_t *)ctx->build.quad_ids.ptr;
     s.spheres = (const crt_sphere *)ctx->spheres.ptr; s.quads = (const crt_quad *)ctx->quads.ptr; s.tris = (const crt_tri *)ctx->tris.ptr; s.n_tris = ctx->n_tris;
     s.materials = (const crt_material *)ctx->materials.ptr;
-    s.tex0 = (const uint8_t *)ctx->tex0.ptr; s.tex0_w = ctx->tex0_w; s.tex0_h = ctx->tex0_h; s.n_textures = ctx->n_textures;
+    s.tex0 = (const uint4 *)ctx->tex_fp.ptr; s.tex0_w = ctx->tex0_w; s.tex0_h = ctx->tex0_h; s.n_textures = ctx->n_textures;
     s.tex_table = (const uint4 *)ctx->tex_table.ptr; s.ext = ctx->ext;
     s.dbg_boxes = ctx->n_dbg_boxes ? ctx->dbg_boxes.ptr : nullptr; s.n_dbg_boxes = ctx->n_dbg_boxes;
     return s;
@@ -221,7 +236,7 @@ void crt_destroy(crt_context *ctx) {
     if (!ctx) return;
     if (hipSetDevice(ctx->device) == hipSuccess) {
         hipError_t e = hipStreamSynchronize(ctx->stream); (void)e;
-        DeviceBuffer *all[] = {&ctx->spheres, &ctx->quads, &ctx->tris, &ctx->tris_rest, &ctx->materials, &ctx->tex0, &ctx->tex_table, &ctx->dbg_boxes, &ctx->dbg_scan, &ctx->accum, &ctx->hit_ids, &ctx->stats};
+        DeviceBuffer *all[] = {&ctx->spheres, &ctx->quads, &ctx->tris, &ctx->tris_rest, &ctx->materials, &ctx->tex0, &ctx->tex_fp, &ctx->tex_table, &ctx->dbg_boxes, &ctx->dbg_scan, &ctx->accum, &ctx->hit_ids, &ctx->stats};
         for (DeviceBuffer *b : all) release(*b);
         free_build_state(ctx->build);
         free_wavefront(ctx->wf);
@@ -307,7 +322,7 @@ int crt_scene_upload(crt_context *ctx, const crt_scene_desc *s) {
         size_t texels = 0;
         for (uint32_t i = 0; i < s->n_textures; i++) {
             const crt_texture &t = s->textures[i];
-            if (texels > 0xFFFFFFFFull) return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload: more than 2^32 texels of textures");
+            if (texels + (size_t)t.width * t.height > 0xFFFFFFFFull) return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload: more than 2^32 texels of textures");
             table[4 * i] = (uint32_t)texels; table[4 * i + 1] = t.width; table[4 * i + 2] = t.height; table[4 * i + 3] = 0;
             texels += (size_t)t.width * t.height;
         }
@@ -317,6 +332,12 @@ int crt_scene_upload(crt_context *ctx, const crt_scene_desc *s) {
             CTX_HIP(hipMemcpy((uint8_t *)ctx->tex0.ptr + 4 * (size_t)table[4 * i], t.rgba8, (size_t)t.width * t.height * 4, hipMemcpyHostToDevice));   // synchronous: the caller's pixels may go away after this call
         }
         if ((rc = upload(ctx, ctx->tex_table, table.data(), table.size() * 4))) return rc;
+        if ((rc = alloc(ctx, ctx->tex_fp, texels * 16))) return rc;
+        hipLaunchKernelGGL(k_tex_footprints, dim3((uint32_t)((texels + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->tex0.ptr,
+                           (const uint4 *)ctx->tex_table.ptr, s->n_textures, (uint32_t)texels, (uint4 *)ctx->tex_fp.ptr);
+        CTX_HIP(hipGetLastError());
+        CTX_HIP(hipStreamSynchronize(ctx->stream));
+        release(ctx->tex0);      // the plain texels were staging only: the kernels sample the footprints (16 bytes per texel resident)
         ctx->tex0_w = s->textures[0].width; ctx->tex0_h = s->textures[0].height;
     }
     ctx->have_scene = true;

@@ -28,8 +28,9 @@ struct DeviceScene {
     const crt_tri *tris;
     uint32_t n_tris;            // 0: tri_shade holds no record
     const crt_material *materials;
-    const uint8_t *tex0;        // textures[0], RGBA8 rows top-down (the shader only ever samples index 0, compute.comp:387);
-                                // the scene's other textures follow it in the same allocation (tex_table)
+    const uint4 *tex0;          // textures[0] as bilinear footprints: entry y * w + x = the RGBA8 texels (x, y), (x+1, y), (x, y+1),
+                                // (x+1, y+1) with REPEAT wrap, so a sample is ONE 16-byte load (the shader only ever samples index 0,
+                                // compute.comp:387); the scene's other textures follow it in the same allocation (tex_table)
     uint32_t tex0_w, tex0_h;
     uint32_t n_textures;
     const uint4 *tex_table;     // texture i: {first texel (offset from tex0 in texels), width, height, -}
@@ -105,23 +106,22 @@ CRT_DEV int wrapi(float f, int n) { int i = (int)f % n; return i < 0 ? i + n : i
 // EXT = false: the kernels that run while no extension is set; they do not even test the flag (as a run-time branch with
 // per-lane texture sizes behind it, the test cost k_wf_shade 7 %).
 template <bool EXT>
-CRT_DEV const uint8_t *material_texture(const DeviceScene &sc, uint32_t texIndex, uint32_t &w, uint32_t &h) {
+CRT_DEV const uint4 *material_texture(const DeviceScene &sc, uint32_t texIndex, uint32_t &w, uint32_t &h) {
     w = sc.tex0_w; h = sc.tex0_h;
     if (!EXT || !(sc.ext & CRT_EXT_TEXTURE_INDEX)) return sc.tex0;
     const uint4 e = sc.tex_table[texIndex];
     w = e.y; h = e.z;
-    return sc.tex0 + 4 * (size_t)e.x;
+    return sc.tex0 + (size_t)e.x;
 }
 
 // Alpha channel through the colour fetch's sampler (shade.h sample_texture: bilinear, REPEAT, centres at +0.5).
-CRT_DEV float texture_alpha(const uint8_t *tex, uint32_t w, uint32_t h, float u, float v) {
+CRT_DEV float texture_alpha(const uint4 *tex, uint32_t w, uint32_t h, float u, float v) {
     float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
     float x0f = __builtin_floorf(x), y0f = __builtin_floorf(y);
     float fx = x - x0f, fy = y - y0f;
     int x0 = wrapi(x0f, (int)w), y0 = wrapi(y0f, (int)h);
-    int x1 = x0 + 1 == (int)w ? 0 : x0 + 1, y1 = y0 + 1 == (int)h ? 0 : y0 + 1;
-    const float a00 = (float)tex[4 * ((size_t)y0 * w + (size_t)x0) + 3] / 255.0f, a10 = (float)tex[4 * ((size_t)y0 * w + (size_t)x1) + 3] / 255.0f;
-    const float a01 = (float)tex[4 * ((size_t)y1 * w + (size_t)x0) + 3] / 255.0f, a11 = (float)tex[4 * ((size_t)y1 * w + (size_t)x1) + 3] / 255.0f;
+    const uint4 q = tex[(size_t)y0 * w + (size_t)x0];      // the 2 x 2 footprint (x0, y0), (x1, y0), (x0, y1), (x1, y1)
+    const float a00 = (float)(q.x >> 24) / 255.0f, a10 = (float)(q.y >> 24) / 255.0f, a01 = (float)(q.z >> 24) / 255.0f, a11 = (float)(q.w >> 24) / 255.0f;
     float top = a00 * (1.0f - fx) + a10 * fx;
     float bot = a01 * (1.0f - fx) + a11 * fx;
     return top * (1.0f - fy) + bot * fy;
@@ -139,7 +139,7 @@ CRT_DEV bool tri_alpha_pass(const DeviceScene &sc, uint32_t id, float beta, floa
     const float u = (alpha * c.z + beta * c.w) + gamma * e.x;
     const float v = (alpha * e.y + beta * e.z) + gamma * e.w;
     uint32_t w, h;
-    const uint8_t *tex = material_texture<true>(sc, texIndex, w, h);
+    const uint4 *tex = material_texture<true>(sc, texIndex, w, h);
     return !(texture_alpha(tex, w, h, u, v) < 0.5f);
 }
 

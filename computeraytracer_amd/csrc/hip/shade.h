@@ -19,22 +19,16 @@ CRT_DEV void camera_get_ray(const crt_camera_data &cam, float u, float v, Rng<M>
 
 // RGBA8 UNORM, bilinear, REPEAT, texel centres at +0.5 (vk_initializers.cpp:252-261); plain float weights.
 CRT_DEV V3 unpack_rgb(uint32_t p) { return mk3((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f); }
-CRT_DEV V3 texel(const uint8_t *tex, uint32_t w, int x, int y) { return unpack_rgb(*(const uint32_t *)(tex + 4 * ((size_t)y * w + (size_t)x))); }
-CRT_DEV V3 sample_texture(const uint8_t *tex, uint32_t w, uint32_t h, float u, float v) {
+CRT_DEV V3 sample_texture(const uint4 *tex, uint32_t w, uint32_t h, float u, float v) {
     float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
     float x0f = __builtin_floorf(x), y0f = __builtin_floorf(y);
     float fx = x - x0f, fy = y - y0f;
     int x0 = wrapi(x0f, (int)w), y0 = wrapi(y0f, (int)h);
-    int x1 = x0 + 1 == (int)w ? 0 : x0 + 1, y1 = y0 + 1 == (int)h ? 0 : y0 + 1;
-    V3 t00, t10, t01, t11;
-    if (x1 == x0 + 1) {
-        // the two texels of a row sit side by side (no wrap): one 8-byte load per row instead of two 4-byte ones; the
-        // address path of k_wf_shade is its busiest unit (TA_BUSY 0.75) and these are fully divergent accesses
-        const uint2 top2 = *(const uint2 *)(tex + 4 * ((size_t)y0 * w + (size_t)x0)), bot2 = *(const uint2 *)(tex + 4 * ((size_t)y1 * w + (size_t)x0));
-        t00 = unpack_rgb(top2.x); t10 = unpack_rgb(top2.y); t01 = unpack_rgb(bot2.x); t11 = unpack_rgb(bot2.y);
-    } else {
-        t00 = texel(tex, w, x0, y0); t10 = texel(tex, w, x1, y0); t01 = texel(tex, w, x0, y1); t11 = texel(tex, w, x1, y1);
-    }
+    // One 16-byte load: the texture is resident as footprints (entry (x0, y0) = the four texels of its bilinear sample,
+    // wrap included; crt_scene_upload builds them), because the address path of k_wf_shade is its busiest unit and these
+    // are fully divergent accesses: two 8-byte row loads were 128 of its ~430 address cycles per 64 paths.
+    const uint4 q = tex[(size_t)y0 * w + (size_t)x0];
+    const V3 t00 = unpack_rgb(q.x), t10 = unpack_rgb(q.y), t01 = unpack_rgb(q.z), t11 = unpack_rgb(q.w);
     V3 top = t00 * (1.0f - fx) + t10 * fx;
     V3 bot = t01 * (1.0f - fx) + t11 * fx;
     return top * (1.0f - fy) + bot * fy;
@@ -117,7 +111,7 @@ CRT_DEV bool shade_hit(const DeviceScene &sc, V3 &o, V3 &d, float t, uint32_t id
         if (texIndex != CRT_BAD_INDEX && sc.n_textures > 0) {
             resolve_uv<PRE>(sc, o, d, id, rec, pre);
             uint32_t tw, th;
-            const uint8_t *tex = material_texture<EXT>(sc, texIndex, tw, th);      // always textures[0] (sic, :387) unless CRT_EXT_TEXTURE_INDEX
+            const uint4 *tex = material_texture<EXT>(sc, texIndex, tw, th);      // always textures[0] (sic, :387) unless CRT_EXT_TEXTURE_INDEX
             attenuation = sample_texture(tex, tw, th, rec.u, rec.v);
         }
         o = rec.position; d = normalize3(dir);
