@@ -54,7 +54,9 @@ const char *crt_last_error(const crt_context *ctx);
 int crt_configure(crt_context *ctx, const crt_config *cfg);
 
 /* Replaces the five upload_buffer calls + texture descriptors of
- * init_descriptors (vk_engine.cpp:1177-1229).  Invalidates any BVH. */
+ * init_descriptors (vk_engine.cpp:1177-1229).  Invalidates any BVH.  Textures (RGBA8 rows, top-down) are copied during
+ * the call and kept on the device as bilinear footprints, 16 bytes per texel (four times the upload; fewer than 2^32
+ * texels in all). */
 int crt_scene_upload(crt_context *ctx, const crt_scene_desc *scene);
 
 /* Limits (every one is checked and reported as an error, never a wrong image): fewer than 2^30 primitives of a kind
