@@ -220,37 +220,49 @@ __global__ void k_pack(BuildInput in, uint32_t n, const uint32_t *vals, const ui
 }
 
 // delta(i, j): length of the common prefix of keys i and j, ties broken by the index (Karras 2012, section 4).
-__device__ __forceinline__ int delta(const uint64_t *keys, int n, int i, int j) {
+// The keys around a workgroup's 256 nodes sit in LDS (kHierWin on either side): most probes of the searches below stay
+// inside that window, and a wave is as slow as its lane with the longest chain of dependent probes.
+constexpr int kHierWin = 384;
+constexpr int kHierKeys = 256 + 2 * kHierWin;
+__device__ __forceinline__ int delta(const uint64_t *keys, const uint64_t *s_keys, int win_lo, int n, uint64_t a, int i, int j) {
     if (j < 0 || j >= n) return -1;
-    uint64_t a = keys[i], b = keys[j];
+    const int w = j - win_lo;
+    const uint64_t b = (w >= 0 && w < kHierKeys) ? s_keys[w] : keys[j];
     if (a == b) return 64 + __clz((uint32_t)i ^ (uint32_t)j);
     return __clzll((long long)(a ^ b));
 }
 
 // Node numbering: inner i in [0, n-2], leaf j -> (n - 1) + j.  parent[] is indexed by that numbering.
 // unpack_vals (packed keys only): vals[i] = the index in the key's low bits, written on the way.
-__global__ void k_hierarchy(int n, const uint64_t *keys, uint32_t *child_l, uint32_t *child_r, uint32_t *parent,
-                            uint32_t *range_lo, uint32_t *range_hi, uint32_t *unpack_vals, uint32_t idx_mask) {
+__global__ __launch_bounds__(256) void k_hierarchy(int n, const uint64_t *keys, uint32_t *child_l, uint32_t *child_r, uint32_t *parent,
+                                                   uint32_t *range_lo, uint32_t *range_hi, uint32_t *unpack_vals, uint32_t idx_mask) {
+    __shared__ uint64_t s_keys[kHierKeys];
+    const int win_lo = (int)(blockIdx.x * blockDim.x) - kHierWin;
+    for (int t = threadIdx.x; t < kHierKeys; t += 256) { const int g = win_lo + t; s_keys[t] = (g >= 0 && g < n) ? keys[g] : 0ull; }
+    __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
+    const uint64_t ki = s_keys[i - win_lo];
     if (unpack_vals) {
-        unpack_vals[i] = (uint32_t)keys[i] & idx_mask;
+        unpack_vals[i] = (uint32_t)ki & idx_mask;
         if (i == n - 2) unpack_vals[n - 1] = (uint32_t)keys[n - 1] & idx_mask;
     }
-    int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
-    int dmin = delta(keys, n, i, i - d);
+#define DELTA(j) delta(keys, s_keys, win_lo, n, ki, i, (j))
+    int d = (DELTA(i + 1) - DELTA(i - 1)) >= 0 ? 1 : -1;
+    int dmin = DELTA(i - d);
     int lmax = 2;
-    while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    while (DELTA(i + lmax * d) > dmin) lmax *= 2;
     int l = 0;
     for (int t = lmax / 2; t >= 1; t /= 2)
-        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+        if (DELTA(i + (l + t) * d) > dmin) l += t;
     int j = i + l * d;
-    int dnode = delta(keys, n, i, j);
+    int dnode = DELTA(j);
     int s = 0;
     for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
-        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (DELTA(i + (s + t) * d) > dnode) s += t;
         if (t <= 1) break;
     }
+#undef DELTA
     int gamma = i + s * d + min(d, 0);
     uint32_t left = (min(i, j) == gamma) ? (uint32_t)(n - 1 + gamma) : (uint32_t)gamma;
     uint32_t right = (max(i, j) == gamma + 1) ? (uint32_t)(n - 1 + gamma + 1) : (uint32_t)(gamma + 1);
