@@ -302,7 +302,7 @@ __device__ __forceinline__ void write_child(float4 *pair_half, int n, uint32_t c
 // back (the eight L2s are not coherent with each other), and with one such fence per thread and level a
 // 10 M-triangle refit took 79 ms (47 ms with agent scope only on the ~4 % of nodes that span a workgroup boundary).
 // So the refit runs in stages and never leaves workgroup scope:
-//   stage 1   a workgroup owns 256 consecutive leaves and climbs while the parent's range stays inside them: both
+//   stage 1   a workgroup owns kRefitLeaves consecutive leaves and climbs while the parent's range stays inside them: both
 //             climbers of such a node are waves of this workgroup, on one CU behind one L1.  A climber whose parent
 //             reaches outside parks its (finished) node in the workgroup's continuation list;
 //   stage s   a workgroup owns 64 ranges of stage s-1, resumes their parked climbers and climbs while the parent
@@ -314,7 +314,10 @@ __device__ __forceinline__ void write_child(float4 *pair_half, int n, uint32_t c
 // (A = surface area; entering a node costs one pair fetch + two slab tests = Ct), a subtree of one kind with at most
 // max_leaf primitives becomes a single leaf when that is not more expensive.  Its primitives are contiguous in the
 // sorted arrays because an LBVH subtree covers a contiguous Morton range.
-constexpr uint32_t kRefitLeaves = 256;     // leaves per stage-1 workgroup
+#ifndef CRT_REFIT_LEAVES
+#define CRT_REFIT_LEAVES 512
+#endif
+constexpr uint32_t kRefitLeaves = CRT_REFIT_LEAVES;     // leaves per stage-1 workgroup (10 M triangles: 128 / 256 / 512 / 1024 build in 2.86 / 2.70 / 2.62 / 2.84 ms)
 constexpr uint32_t kRefitFan = 64;         // ranges of the previous stage per workgroup of a later stage
 constexpr uint32_t kRefitCap = 256;        // continuation entries per workgroup
 
@@ -374,7 +377,7 @@ __device__ __forceinline__ void refit_climb(const RefitArgs &A, uint32_t node, f
 // end of its range), so a level costs one round of independent global loads (parent, range, children) plus the
 // 128 bytes of the pair it emits; only parked nodes are written to the global node arrays for the next stage.
 __global__ __launch_bounds__(kRefitLeaves) void k_refit_leaves(RefitArgs A, uint32_t *list_out, uint32_t *count_out) {
-    __shared__ float4 s_lo[2 * kRefitLeaves], s_hi[2 * kRefitLeaves], s_info[2 * kRefitLeaves];      // [0, 256): inner nodes, [256, 512): leaves
+    __shared__ float4 s_lo[2 * kRefitLeaves], s_hi[2 * kRefitLeaves], s_info[2 * kRefitLeaves];      // first half: inner nodes, second half: leaves
     __shared__ uint32_t s_flag[kRefitLeaves];
     __shared__ uint32_t s_parent[kRefitLeaves], s_rlo[kRefitLeaves], s_rhi[kRefitLeaves], s_cl[kRefitLeaves], s_cr[kRefitLeaves];
     __shared__ uint32_t s_count;
