@@ -25,7 +25,7 @@ def ctx():
     c.close()
 
 
-def _cutout_scene(w, h, n_tris=700, seed=3):
+def _cutout_scene(w, h, n_tris=700, seed=3, tex_sizes=((16, 16), (8, 32), (5, 7))):
     """Layers of random triangles over book1's ground sphere.  Three textured Lambertians (textures of different sizes,
     alpha in {0, 255} blocks, smooth ramps and values next to the 0.5 cut), one untextured Lambertian, one metal, a
     light.  Texture coordinates run past [0, 1] on purpose (REPEAT)."""
@@ -37,7 +37,7 @@ def _cutout_scene(w, h, n_tris=700, seed=3):
     mats["fuzziness"] = [0, 0, 0, 0, 0.3, 0]
     mats["textureIndex"] = [0, 1, 2, abi.BAD_INDEX, abi.BAD_INDEX, abi.BAD_INDEX]
     textures = []
-    for (th, tw) in [(16, 16), (8, 32), (5, 7)]:
+    for (th, tw) in tex_sizes:
         t = rs.randint(0, 256, (th, tw, 4)).astype(np.uint8)
         a = np.where(rs.uniform(size=(th, tw)) < 0.45, 0, 255)
         a[::3, ::2] = rs.randint(0, 256, a[::3, ::2].shape)          # anything
@@ -97,6 +97,21 @@ def test_extensions_change_the_picture_and_off_is_the_reference(ctx):
             assert not np.array_equal(out[i][0], out[j][0])
     assert np.array_equal(out[0][1], out[1][1])            # textureIndex does not move a primary hit
     assert (out[0][1] != out[2][1]).mean() > 0.02          # the alpha test does
+
+
+@pytest.mark.parametrize("tracer", [abi.TRACER_MEGAKERNEL, abi.TRACER_WAVEFRONT], ids=["megakernel", "wavefront"])
+def test_degenerate_texture_sizes(ctx, tracer):
+    """1 x 1, 1 x 3 and 2 x 1 textures: every bilinear footprint wraps onto itself or its only neighbour."""
+    w, h, n_iter = 64, 48, 2
+    scene = _cutout_scene(w, h, n_tris=300, tex_sizes=((1, 1), (1, 3), (2, 1)))
+    ref = orc.render(scene, [scene.params_for(i + 1, s) for i, s in enumerate(abi.frame_seeds(0, n_iter))], w, h,
+                     flags=orc.TRAVERSE_BRUTE | orc.EXT_TEXTURE_INDEX | orc.EXT_ALPHA_TEST)
+    img, ids, _ = _render(ctx, scene, w, h, n_iter, abi.BVH_SAH_REFINE | abi.BVH_WIDE, tracer, abi.EXT_TEXTURE_INDEX | abi.EXT_ALPHA_TEST)
+    assert np.array_equal(ids, ref[1])
+    assert np.array_equal(img.view(np.uint32), ref[0].view(np.uint32))
+    ref0 = orc.render(scene, [scene.params_for(i + 1, s) for i, s in enumerate(abi.frame_seeds(0, n_iter))], w, h, flags=orc.TRAVERSE_BRUTE)
+    img0, ids0, _ = _render(ctx, scene, w, h, n_iter, abi.BVH_SAH_REFINE | abi.BVH_WIDE, tracer, 0)
+    assert np.array_equal(ids0, ref0[1]) and np.array_equal(img0.view(np.uint32), ref0[0].view(np.uint32))
 
 
 @pytest.mark.parametrize("bvh", BVHS, ids=BVH_IDS)
