@@ -18,8 +18,9 @@
 //              (loaded lazily, only when a leaf slot is actually hit); inner slot = its node index (diagnostic);
 //              empty slot = kLeafTag | 3 << 29
 //   float4 6,7 unused
-// Child box of slot s on axis a = [o_a + qlo * 2^e_a, o_a + qhi * 2^e_a] as REAL numbers; the build checks in
-// double precision that this interval contains the child's box of the pair BVH.  Empty slots have qlo = 255,
+// Child box of slot s on axis a = [o_a + qlo * 2^e_a, o_a + qhi * 2^e_a] as REAL numbers; it contains the child's box of
+// the pair BVH by construction (wide_emit rounds outwards with 2^-10 of a grid step of slack against its own single
+// rounding; tests/test_gpu_parity.py::_check_wide verifies the containment exactly).  Empty slots have qlo = 255,
 // qhi = 0.
 //
 // Slots are assigned so that slot ^ octant(ray) is a front-to-back visiting order (Ylitie, Karras, Laine 2017):
