@@ -288,6 +288,15 @@ template <typename F> static int guarded(F &&f) {
     catch (const std::exception &e) { set_host_error(e.what()); return CRT_ERR_IO; }
 }
 
+// malloc'ed copy handed to the caller (crt_free); never null on success, never a zero-length memcpy from a null source
+template <typename T> static bool copy_out(const std::vector<T> &v, void **out) {
+    void *p = malloc(v.size() * sizeof(T) + 1);
+    if (!p) { set_host_error("out of memory while reading an asset"); return false; }
+    if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
+    *out = p;
+    return true;
+}
+
 extern "C" {
 
 int crt_lz4_compress_bound(int n) { return lz4_bound(n); }
@@ -298,8 +307,7 @@ int crt_obj_to_vertices(const char *path, float **vertices_pncv, uint32_t *n_ver
     return guarded([&]() -> int {
     std::vector<MeshVertex> v; std::string err;
     if (!load_obj(path, v, err)) { set_host_error(err); return CRT_ERR_IO; }
-    *vertices_pncv = (float *)malloc(v.size() * sizeof(MeshVertex) + 1);
-    memcpy(*vertices_pncv, v.data(), v.size() * sizeof(MeshVertex));
+    if (!copy_out(v, (void **)vertices_pncv)) return CRT_ERR_IO;
     *n_vertices = (uint32_t)v.size();
     return CRT_OK;
     });
@@ -311,6 +319,7 @@ int crt_load_obj(const char *path, uint32_t material_index, crt_tri **tris, uint
     if (!load_mesh_file(path, v, err)) { set_host_error(err); return CRT_ERR_IO; }
     uint32_t n = (uint32_t)(v.size() / 3);
     crt_tri *t = (crt_tri *)calloc(n ? n : 1, sizeof(crt_tri));
+    if (!t) { set_host_error("out of memory while reading an asset"); return CRT_ERR_IO; }
     for (uint32_t i = 0; i < n; i++) {
         const MeshVertex &a = v[3 * i], &b = v[3 * i + 1], &c = v[3 * i + 2];
         memcpy(t[i].v0, a.pos, 12); memcpy(t[i].v1, b.pos, 12); memcpy(t[i].v2, c.pos, 12);
@@ -327,10 +336,8 @@ int crt_mesh_file_read(const char *path, float **vertices_pncv, uint32_t *n_vert
     return guarded([&]() -> int {
     std::vector<MeshVertex> v; std::vector<uint32_t> idx; std::string err;
     if (!load_mesh_container(path, v, idx, err)) { set_host_error(err); return CRT_ERR_IO; }
-    *vertices_pncv = (float *)malloc(v.size() * sizeof(MeshVertex) + 1);
-    memcpy(*vertices_pncv, v.data(), v.size() * sizeof(MeshVertex));
-    *indices = (uint32_t *)malloc(idx.size() * 4 + 1);
-    memcpy(*indices, idx.data(), idx.size() * 4);
+    if (!copy_out(v, (void **)vertices_pncv)) return CRT_ERR_IO;
+    if (!copy_out(idx, (void **)indices)) { free(*vertices_pncv); *vertices_pncv = nullptr; return CRT_ERR_IO; }
     *n_vertices = (uint32_t)v.size(); *n_indices = (uint32_t)idx.size();
     return CRT_OK;
     });
@@ -361,9 +368,10 @@ int crt_mesh_file_write(const char *path, const float *vertices_pncv, uint32_t n
     snprintf(buf, sizeof buf, "\"vertex_buffer_size\":%zu,\"vertex_format\":\"PNCV_F32\"}", vbs);
     f.json += buf;
     if (vbs + ibs > 2147483647u - 65536u) { set_host_error("mesh larger than the LZ4 block format addresses (2 GiB)"); return CRT_ERR_INVALID; }
+    if ((vbs && !vertices_pncv) || (ibs && !indices)) { set_host_error("crt_mesh_file_write: a non-empty array has a null pointer"); return CRT_ERR_INVALID; }
     std::vector<uint8_t> merged(vbs + ibs);
-    memcpy(merged.data(), vertices_pncv, vbs);
-    memcpy(merged.data() + vbs, indices, ibs);
+    if (vbs) memcpy(merged.data(), vertices_pncv, vbs);
+    if (ibs) memcpy(merged.data() + vbs, indices, ibs);
     f.blob.resize((size_t)lz4_bound((int)merged.size()));
     int c = lz4_compress(merged.data(), (int)merged.size(), f.blob.data(), (int)f.blob.size());
     if (c < 0) { set_host_error("LZ4 compression failed"); return CRT_ERR_INVALID; }
@@ -378,8 +386,7 @@ int crt_texture_file_read(const char *path, uint8_t **rgba8, uint32_t *width, ui
     return guarded([&]() -> int {
     std::vector<uint8_t> px; std::string err;
     if (!load_texture_file(path, px, *width, *height, err)) { set_host_error(err); return CRT_ERR_IO; }
-    *rgba8 = (uint8_t *)malloc(px.size() + 1);
-    memcpy(*rgba8, px.data(), px.size());
+    if (!copy_out(px, (void **)rgba8)) return CRT_ERR_IO;
     return CRT_OK;
     });
 }
