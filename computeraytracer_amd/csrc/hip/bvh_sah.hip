@@ -149,6 +149,41 @@ __device__ __forceinline__ unsigned long long wave_sort(unsigned long long key, 
 // (ballot + prefix count + one ds_permute each), which keeps each side sorted on every axis.  The orders are therefore
 // sorted once, up front: re-sorting every level (three 21-stage bitonic networks) was two thirds of this function's
 // dependent shuffles.
+// Segmented inclusive scans over the wave on the VALU (DPP) instead of through the LDS crossbar: the wave-subtree loop
+// spent half of its cycles waiting for ds_bpermute results (SQ_WAIT_ANY 0.49, SQ_WAIT_INST_LDS 0.24 of the wave cycles).
+// Lane l combines with lanes [s0, l) of its segment: four row_shr steps inside the 16-lane rows, then row_bcast:15 into
+// rows 1 and 3 and row_bcast:31 into rows 2 and 3 carry the finished part of the segment across the row borders (a lane
+// takes them only when its segment starts before its row / before lane 32).  `old` = the operation's identity, which is
+// what a lane keeps when DPP gives it no source.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false); }
+template <bool MAX>
+__device__ __forceinline__ float seg_scan(float v, uint32_t lane, uint32_t s0) {
+    const float id = MAX ? -kFInf : kFInf;
+    const uint32_t idu = __float_as_uint(id);
+#define CRT_SEG_STEP(CTRL, RM, COND) { float o = __uint_as_float(dpp_u<CTRL, RM>(idu, __float_as_uint(v))); o = (COND) ? o : id; v = MAX ? fmaxf(v, o) : fminf(v, o); }
+    CRT_SEG_STEP(0x111, 0xF, lane >= s0 + 1u)
+    CRT_SEG_STEP(0x112, 0xF, lane >= s0 + 2u)
+    CRT_SEG_STEP(0x114, 0xF, lane >= s0 + 4u)
+    CRT_SEG_STEP(0x118, 0xF, lane >= s0 + 8u)
+    CRT_SEG_STEP(0x142, 0xA, s0 < (lane & 48u))
+    CRT_SEG_STEP(0x143, 0xC, s0 < 32u)
+#undef CRT_SEG_STEP
+    return v;
+}
+// The same for the minimum of a 64-bit key held as two words.
+__device__ __forceinline__ void seg_scan_min64(uint32_t &hi, uint32_t &lo, uint32_t lane, uint32_t s0) {
+#define CRT_SEG_STEP(CTRL, RM, COND) { const uint32_t oh = dpp_u<CTRL, RM>(0xFFFFFFFFu, hi), ol = dpp_u<CTRL, RM>(0xFFFFFFFFu, lo); \
+        const bool take = (COND) && (oh < hi || (oh == hi && ol < lo)); hi = take ? oh : hi; lo = take ? ol : lo; }
+    CRT_SEG_STEP(0x111, 0xF, lane >= s0 + 1u)
+    CRT_SEG_STEP(0x112, 0xF, lane >= s0 + 2u)
+    CRT_SEG_STEP(0x114, 0xF, lane >= s0 + 4u)
+    CRT_SEG_STEP(0x118, 0xF, lane >= s0 + 8u)
+    CRT_SEG_STEP(0x142, 0xA, s0 < (lane & 48u))
+    CRT_SEG_STEP(0x143, 0xC, s0 < 32u)
+#undef CRT_SEG_STEP
+}
+
 __device__ __forceinline__ uint32_t lane_push(uint32_t to_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_permute((int)(to_lane << 2), (int)v); }
 __device__ __forceinline__ uint32_t lane_pull(uint32_t from_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)v); }
 
@@ -189,40 +224,40 @@ __device__ void sah_wave_subtree(const SahGroupArgs &g, SahLds &L, uint32_t grou
         const uint32_t len = s1 - s0;
         float best = kFInf, nlo[3], nhi[3];
         uint32_t best_ax = 0;
+        // The right-hand boxes are prefix scans too, over the wave in reverse: lane l' of the reversed view holds position
+        // 63 - l', whose segment starts (reversed) at 64 - s1.
+        const uint32_t rev = 63u - lane, s0r = 64u - lane_pull(rev, s1);
 #pragma unroll
         for (int ax = 0; ax < 3; ax++) {
+            const uint32_t ord_rev = lane_pull(rev, ord[ax]);
             float llo[3], lhi[3], rlo[3], rhi[3];
 #pragma unroll
             for (int d = 0; d < 3; d++) {
-                llo[d] = rlo[d] = ax == 0 ? blo[d] : __shfl(lo[d], (int)ord[ax]);
-                lhi[d] = rhi[d] = ax == 0 ? bhi[d] : __shfl(hi[d], (int)ord[ax]);
+                llo[d] = ax == 0 ? blo[d] : __shfl(lo[d], (int)ord[ax]);
+                lhi[d] = ax == 0 ? bhi[d] : __shfl(hi[d], (int)ord[ax]);
+                rlo[d] = __shfl(lo[d], (int)ord_rev);
+                rhi[d] = __shfl(hi[d], (int)ord_rev);
             }
 #pragma unroll
-            for (uint32_t off = 1; off < 64; off <<= 1) {             // inclusive scans inside the segment: left box up to me, right box from me
-                const bool tl = lane >= s0 + off, tr = lane + off < s1;
-#pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    const float a0 = __shfl_up(llo[d], off), a1 = __shfl_up(lhi[d], off), b0 = __shfl_down(rlo[d], off), b1 = __shfl_down(rhi[d], off);
-                    llo[d] = fminf(llo[d], tl ? a0 : kFInf); lhi[d] = fmaxf(lhi[d], tl ? a1 : -kFInf);
-                    rlo[d] = fminf(rlo[d], tr ? b0 : kFInf); rhi[d] = fmaxf(rhi[d], tr ? b1 : -kFInf);
-                }
+            for (int d = 0; d < 3; d++) {      // left box up to me; (reversed) right box from me
+                llo[d] = seg_scan<false>(llo[d], lane, s0); lhi[d] = seg_scan<true>(lhi[d], lane, s0);
+                rlo[d] = seg_scan<false>(rlo[d], lane, s0r); rhi[d] = seg_scan<true>(rhi[d], lane, s0r);
             }
             if (ax == 0) {
 #pragma unroll
-                for (int d = 0; d < 3; d++) { nlo[d] = __shfl(rlo[d], (int)s0); nhi[d] = __shfl(rhi[d], (int)s0); }      // the segment's box
+                for (int d = 0; d < 3; d++) { nlo[d] = __shfl(llo[d], (int)(s1 - 1u)); nhi[d] = __shfl(lhi[d], (int)(s1 - 1u)); }      // the segment's box
             }
 #pragma unroll
-            for (int d = 0; d < 3; d++) { rlo[d] = __shfl_down(rlo[d], 1); rhi[d] = __shfl_down(rhi[d], 1); }             // right box = everything after me
+            for (int d = 0; d < 3; d++) { rlo[d] = __shfl(rlo[d], (int)((62u - lane) & 63u)); rhi[d] = __shfl(rhi[d], (int)((62u - lane) & 63u)); }   // right box = everything after me
             const uint32_t nl = lane - s0 + 1u, nr = s1 - lane - 1u;
             float cost = half_area3(llo, lhi) * (float)nl + half_area3(rlo, rhi) * (float)nr;
             cost = (open && lane + 1u < s1 && cost < kFInf) ? cost : kFInf;      // also turns a NaN into "invalid"
             if (cost < best) { best = cost; best_ax = (uint32_t)ax; }
         }
         // cheapest candidate of the segment: inclusive min-scan, read at the segment's last lane
-        unsigned long long bk = ((unsigned long long)__float_as_uint(best) << 32) | (best_ax << 8) | lane;
-#pragma unroll
-        for (uint32_t off = 1; off < 64; off <<= 1) { const unsigned long long o = __shfl_up(bk, off); if (lane >= s0 + off && o < bk) bk = o; }
-        bk = __shfl(bk, (int)(s1 - 1u));
+        uint32_t bk_hi = __float_as_uint(best), bk_lo = (best_ax << 8) | lane;
+        seg_scan_min64(bk_hi, bk_lo, lane, s0);
+        const unsigned long long bk = ((unsigned long long)(uint32_t)__shfl((int)bk_hi, (int)(s1 - 1u)) << 32) | (uint32_t)__shfl((int)bk_lo, (int)(s1 - 1u));
         const float split_cost = __uint_as_float((uint32_t)(bk >> 32));
         const bool valid = split_cost < kFInf;
         const uint32_t bax = valid ? ((uint32_t)bk >> 8) & 3u : 0u;            // no finite candidate: halve the axis-0 order
