@@ -52,7 +52,7 @@ namespace crt {
 constexpr uint32_t kWideLeafTag = 0x80000000u;
 constexpr uint32_t kWideEmptyLink = kWideLeafTag | (3u << 29);
 
-struct WideChild { float lo[3], hi[3]; uint32_t link, count, budget; };
+struct WideChild { float lo[3], hi[3]; uint32_t link, count, budget, eff; };      // eff: the child's eff table (table-driven collapse)
 
 
 __device__ __forceinline__ bool pad_leaf(uint32_t count) { return count != 0u && (count & 0x0FFFFFFFu) == 0u; }
@@ -61,13 +61,17 @@ __device__ __forceinline__ void read_half(const float4 *half, WideChild &c) {
     float4 a = half[0], b = half[1];
     c.lo[0] = a.x; c.lo[1] = a.y; c.lo[2] = a.z; c.link = __float_as_uint(a.w);
     c.hi[0] = b.x; c.hi[1] = b.y; c.hi[2] = b.z; c.count = __float_as_uint(b.w);
-    c.budget = 1u;
+    c.budget = 1u; c.eff = 0u;
 }
 
 // ---- the table ----------------------------------------------------------------------------------------------------
 // choice word of inner node n (64 bits): bits 3 (j - 2) .. +2 = k of the best split of j slots between its children
-// (j = 2 .. 8: left gets k, right j - k); bits 21 + 3 (i - 1) .. +2 = eff(i), i = 1 .. 7: the number of slots n actually
-// uses when it is offered i (1 = n stays a wide node of its own).
+// (j = 2 .. 8: left gets k, right j - k); bits 21 .. 41 = the eff table of its LEFT child, bits 42 .. 62 that of its right
+// child, where eff(i), i = 1 .. 7, three bits each, is the number of slots a node actually uses when it is offered i
+// (1 = it stays a wide node of its own; 0 for a leaf).  A node's own table sits in its parent's word, so that the
+// collapse knows whether a child dissolves from the word it loaded together with the child's pair: one dependent
+// round trip per dissolved child instead of two.  (cost row of a node: c(1..7) and, as the eighth word, its own table,
+// from where the parent's entry takes it.)
 constexpr uint32_t kDpLevels = kPairLevels;      // pair trees are at most 96 deep (kMaxPairDepth), LBVH ones at most 95
 struct DpLevels { uint32_t start[kDpLevels + 1]; };
 
@@ -96,7 +100,9 @@ __global__ void k_dp_level(const float4 *pairs, const uint32_t *list, uint32_t f
     read_half(pairs + 4 * (size_t)n + 2, b);
     float cl[8], cr[8];                                   // index 1 .. 7
 #pragma unroll
-    for (int k = 1; k < 8; k++) { cl[k] = a.count == 0u ? cost[7 * (size_t)a.link + (k - 1)] : 0.0f; cr[k] = b.count == 0u ? cost[7 * (size_t)b.link + (k - 1)] : 0.0f; }
+    for (int k = 1; k < 8; k++) { cl[k] = a.count == 0u ? cost[8 * (size_t)a.link + (k - 1)] : 0.0f; cr[k] = b.count == 0u ? cost[8 * (size_t)b.link + (k - 1)] : 0.0f; }
+    const unsigned long long eff_l = a.count == 0u ? (unsigned long long)__float_as_uint(cost[8 * (size_t)a.link + 7]) : 0ull;
+    const unsigned long long eff_r = b.count == 0u ? (unsigned long long)__float_as_uint(cost[8 * (size_t)b.link + 7]) : 0ull;
     float lo[3], hi[3];
 #pragma unroll
     for (int ax = 0; ax < 3; ax++) { lo[ax] = fminf(a.lo[ax], b.lo[ax]); hi[ax] = fmaxf(a.hi[ax], b.hi[ax]); }
@@ -122,11 +128,13 @@ __global__ void k_dp_level(const float4 *pairs, const uint32_t *list, uint32_t f
         c[k] = take ? dist[k] : c[k - 1];
         eff[k] = take ? (uint32_t)k : eff[k - 1];
     }
-    unsigned long long w = 0ull;
+    unsigned long long w = (eff_l << 21) | (eff_r << 42);
+    uint32_t own = 0u;
 #pragma unroll
     for (int j = 2; j <= 8; j++) w |= (unsigned long long)split[j] << (3 * (j - 2));
 #pragma unroll
-    for (int k = 1; k < 8; k++) { w |= (unsigned long long)eff[k] << (21 + 3 * (k - 1)); cost[7 * (size_t)n + (k - 1)] = c[k]; }
+    for (int k = 1; k < 8; k++) { own |= eff[k] << (3 * (k - 1)); cost[8 * (size_t)n + (k - 1)] = c[k]; }
+    cost[8 * (size_t)n + 7] = __uint_as_float(own);
     choice[n] = w;
 }
 
@@ -136,7 +144,7 @@ __global__ void k_dp_level(const float4 *pairs, const uint32_t *list, uint32_t f
 __device__ __forceinline__ void take_if(WideChild &dst, const WideChild &v, bool p) {      // field-wise selects, never a conditional store
 #pragma unroll
     for (int a = 0; a < 3; a++) { dst.lo[a] = p ? v.lo[a] : dst.lo[a]; dst.hi[a] = p ? v.hi[a] : dst.hi[a]; }
-    dst.link = p ? v.link : dst.link; dst.count = p ? v.count : dst.count; dst.budget = p ? v.budget : dst.budget;
+    dst.link = p ? v.link : dst.link; dst.count = p ? v.count : dst.count; dst.budget = p ? v.budget : dst.budget; dst.eff = p ? v.eff : dst.eff;
 }
 struct WideSet {
     WideChild c[8];
@@ -159,28 +167,30 @@ __device__ __forceinline__ void wide_emit(const float4 *pairs, const unsigned lo
     {
         WideSet S;
 #pragma unroll
-        for (int k = 0; k < 8; k++) { for (int a = 0; a < 3; a++) { S.c[k].lo[a] = 0.0f; S.c[k].hi[a] = 0.0f; } S.c[k].link = 0u; S.c[k].count = 0u; S.c[k].budget = 1u; }
+        for (int k = 0; k < 8; k++) { for (int a = 0; a < 3; a++) { S.c[k].lo[a] = 0.0f; S.c[k].hi[a] = 0.0f; } S.c[k].link = 0u; S.c[k].count = 0u; S.c[k].budget = 1u; S.c[k].eff = 0u; }
         int n = 0;
         {
             WideChild a, b;
             read_half(pairs + 4 * (size_t)src, a);
             read_half(pairs + 4 * (size_t)src + 2, b);
-            if (choice) { const uint32_t k8 = (uint32_t)(choice[src] >> 18) & 7u; a.budget = k8; b.budget = 8u - k8; }      // best split of 8 slots
+            if (choice) {      // best split of 8 slots, and the children's own tables
+                const unsigned long long w = choice[src];
+                const uint32_t k8 = (uint32_t)(w >> 18) & 7u;
+                a.budget = k8; b.budget = 8u - k8; a.eff = (uint32_t)(w >> 21) & 0x1FFFFFu; b.eff = (uint32_t)(w >> 42) & 0x1FFFFFu;
+            }
             if (!pad_leaf(a.count)) { S.set(n, a); n++; }
             if (!pad_leaf(b.count)) { S.set(n, b); n++; }
         }
         while (n < 8) {
             int best = -1; float best_area = -1.0f; uint32_t best_link = 0, best_budget = 1;
-            unsigned long long best_word = 0ull;
             if (choice) {
                 // an inner child that the table dissolves when offered its budget (eff > 1); any order gives the same set
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     if (k >= n || S.c[k].count != 0u || S.c[k].budget < 2u || best >= 0) continue;
-                    const unsigned long long w = choice[S.c[k].link];
                     const uint32_t bud = S.c[k].budget > 7u ? 7u : S.c[k].budget;
-                    const uint32_t eff = (uint32_t)(w >> (21 + 3 * (bud - 1u))) & 7u;
-                    if (eff > 1u) { best = k; best_link = S.c[k].link; best_budget = eff; best_word = w; }
+                    const uint32_t eff = (S.c[k].eff >> (3 * (bud - 1u))) & 7u;
+                    if (eff > 1u) { best = k; best_link = S.c[k].link; best_budget = eff; }
                     else S.c[k].budget = 1u;      // stays a wide node of its own: do not look at it again
                 }
             } else {
@@ -195,7 +205,11 @@ __device__ __forceinline__ void wide_emit(const float4 *pairs, const unsigned lo
             WideChild a, b;
             read_half(pairs + 4 * (size_t)best_link, a);
             read_half(pairs + 4 * (size_t)best_link + 2, b);
-            if (choice) { const uint32_t kk = (uint32_t)(best_word >> (3 * (best_budget - 2u))) & 7u; a.budget = kk; b.budget = best_budget - kk; }
+            if (choice) {      // loaded together with the pair: the split of the slots it was granted and its children's tables
+                const unsigned long long w = choice[best_link];
+                const uint32_t kk = (uint32_t)(w >> (3 * (best_budget - 2u))) & 7u;
+                a.budget = kk; b.budget = best_budget - kk; a.eff = (uint32_t)(w >> 21) & 0x1FFFFFu; b.eff = (uint32_t)(w >> 42) & 0x1FFFFFu;
+            }
             const bool pa = pad_leaf(a.count), pb = pad_leaf(b.count);
             if (pa && pb) { S.set(best, S.get(n - 1)); n--; continue; }
             if (pa) { S.set(best, b); continue; }
@@ -403,7 +417,7 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
     const unsigned long long *choice = nullptr;
     if (!greedy && st.levels_measured && st.n_pairs > 1) {
         const uint32_t np = st.n_pairs;
-        if (!ensure_w(st.dp_cost, (size_t)np * 7 * 4, err) || !ensure_w(st.dp_choice, (size_t)np * 8, err) || !ensure_w(st.dp_list, (size_t)np * 4, err)) return false;
+        if (!ensure_w(st.dp_cost, (size_t)np * 8 * 4, err) || !ensure_w(st.dp_choice, (size_t)np * 8, err) || !ensure_w(st.dp_list, (size_t)np * 4, err)) return false;
         uint32_t *cursor = (uint32_t *)st.dp_hist.ptr + kDpLevels;      // zeroed by measure_pair_depths
         DpLevels lv; lv.start[0] = 0; lv.start[1] = 0;
         for (uint32_t d = 1; d < kDpLevels; d++) lv.start[d + 1] = lv.start[d] + st.level_hist[d];
