@@ -33,6 +33,7 @@ struct BuildState {
     DeviceBuffer tri_shade;        // 64-byte shading record per triangle, input order (bvh_build.hip: write_tri_shade)
     // 8-wide quantised nodes (bvh_wide.hip, CRT_BVH_WIDE): n_wide nodes of kWideStrideF4 float4 each, BFS order
     DeviceBuffer wide, wide_queue[2], wide_levels_dev;
+    uint32_t wide_cap = 0;     // nodes the `wide` allocation was laid out for: the links start kWideStrideF4 * wide_cap float4 in
     DeviceBuffer dp_cost, dp_choice, dp_parent, dp_depth, dp_list, dp_hist;      // collapse table (bvh_wide.hip)
     DeviceBuffer refit_list[2], refit_count[2];      // parked climbers between the stages of the LBVH refit
     uint32_t n_wide = 0, wide_levels = 0;
@@ -41,7 +42,8 @@ struct BuildState {
     uint32_t level_hist[128] = {};                   // pairs per depth (root = 1)
 };
 
-constexpr uint32_t kWideStrideF4 = 8;     // 128-byte node stride: the 64 bytes a step loads never straddle a line
+constexpr uint32_t kWideStrideF4 = 4;     // 64-byte nodes (what a step loads): two siblings per 128-byte line; the eight links of node i
+                                          // live apart, at 32 bytes per node, behind the node array (build_wide / wide_links_of)
 constexpr uint32_t kWideMaxLevels = 64;
 constexpr uint32_t kPairLevels = 128;      // bins of the depth histogram (> kMaxPairDepth)
 constexpr uint32_t kMaxPairDepth = 96;    // pair trees deeper than this are refused: a walk pushes at most depth - 1 entries and the
@@ -59,6 +61,7 @@ void free_build_state(BuildState &st);
 struct DeviceSceneHost {       // host-side mirror of DeviceScene (kept POD so context.hip need not include device headers)
     const void *nodes; uint32_t n_pairs;
     const void *wide; uint32_t n_wide, wide_levels;     // 8-wide nodes (null: the wavefront tracer walks the pair BVH)
+    const uint32_t *wide_links;                          // eight link words per wide node
     const void *tri_pack, *sphere_pack, *quad_pack, *tri_shade;
     const uint32_t *sphere_ids, *quad_ids;
     const crt_sphere *spheres; const crt_quad *quads; const crt_tri *tris; uint32_t n_tris;

@@ -163,7 +163,7 @@ struct WideSet {
 // One wide node: collapses the subtree of pair `src` into node `dst` of level `level`; its inner children are appended
 // to q_out (the queue of level + 1) and numbered next_base + position (next_base = nodes of levels 0 .. level).
 __device__ __forceinline__ void wide_emit(const float4 *pairs, const unsigned long long *choice, uint32_t level, uint32_t *level_count,
-                                          uint32_t next_base, uint32_t src, uint32_t dst, uint2 *q_out, float4 *wide, uint32_t stride_f4) {
+                                          uint32_t next_base, uint32_t src, uint32_t dst, uint2 *q_out, float4 *wide, uint4 *links) {
     {
         WideSet S;
 #pragma unroll
@@ -336,28 +336,28 @@ __device__ __forceinline__ void wide_emit(const float4 *pairs, const unsigned lo
 #pragma unroll
             for (int s2 = 0; s2 < 8; s2++) link[s2] = (uint32_t)s2 == sl ? lk : link[s2];
         }
-        float4 *o = wide + (size_t)stride_f4 * dst;
+        float4 *o = wide + (size_t)kWideStrideF4 * dst;
         o[0] = make_float4(__uint_as_float(__float_as_uint(origin[0]) | ebits[0]), __uint_as_float(__float_as_uint(origin[1]) | ebits[1]),
                            __uint_as_float(__float_as_uint(origin[2]) | ebits[2]), __uint_as_float((child_base << 8) | imask));
         o[1] = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
         o[2] = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
         o[3] = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
-        o[4] = make_float4(__uint_as_float(link[0]), __uint_as_float(link[1]), __uint_as_float(link[2]), __uint_as_float(link[3]));
-        o[5] = make_float4(__uint_as_float(link[4]), __uint_as_float(link[5]), __uint_as_float(link[6]), __uint_as_float(link[7]));
+        links[2 * (size_t)dst] = make_uint4(link[0], link[1], link[2], link[3]);
+        links[2 * (size_t)dst + 1] = make_uint4(link[4], link[5], link[6], link[7]);
     }
 }
 
 // level_count[l] = wide nodes of level l (queue length); level l reads queue l & 1 and appends to the other one.
 // Levels below *first_level were already emitted by k_wide_top.
 __global__ __launch_bounds__(128) void k_wide_level(const float4 *pairs, const unsigned long long *choice, uint32_t level, uint32_t *level_count,
-                                                    const uint32_t *first_level, const uint2 *q_in, uint2 *q_out, float4 *wide, uint32_t stride_f4) {
+                                                    const uint32_t *first_level, const uint2 *q_in, uint2 *q_out, float4 *wide, uint4 *links) {
     if (level < *first_level) return;
     const uint32_t n_in = level_count[level];
     uint32_t next_base = 0;                         // nodes of levels 0..level = index of the first node of level + 1
     for (uint32_t l = 0; l <= level; l++) next_base += level_count[l];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
         const uint2 w = q_in[i];
-        wide_emit(pairs, choice, level, level_count, next_base, w.x, w.y, q_out, wide, stride_f4);
+        wide_emit(pairs, choice, level, level_count, next_base, w.x, w.y, q_out, wide, links);
     }
 }
 
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(128) void k_wide_level(const float4 *pairs, const u
 // next (queue entries, level counts) stays inside the workgroup: workgroup-scope release / acquire around the barrier.
 constexpr uint32_t kWideTopThreads = 512;
 __global__ __launch_bounds__(kWideTopThreads) void k_wide_top(const float4 *pairs, const unsigned long long *choice, uint32_t *level_count, uint32_t max_levels,
-                                                              uint32_t *first_level, uint2 *q0, uint2 *q1, float4 *wide, uint32_t stride_f4) {
+                                                              uint32_t *first_level, uint2 *q0, uint2 *q1, float4 *wide, uint4 *links) {
     uint32_t next_base = 0, level = 0;
     for (; level < max_levels; level++) {
         const uint32_t n_in = __hip_atomic_load(&level_count[level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kWideTopThreads) void k_wide_top(const float4 *pair
         uint2 *q_out = (level & 1u) ? q0 : q1;
         if (threadIdx.x < n_in) {
             const uint2 w = q_in[threadIdx.x];
-            wide_emit(pairs, choice, level, level_count, next_base, w.x, w.y, q_out, wide, stride_f4);
+            wide_emit(pairs, choice, level, level_count, next_base, w.x, w.y, q_out, wide, links);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
@@ -407,7 +407,9 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
     if (st.n_pairs == 0) return true;
     if (st.n_pairs >= (1u << 24)) { err = "wide BVH supports fewer than 2^24 nodes"; return false; }
     // every wide node consumes at least one pair, so n_pairs bounds the node count and every level's queue
-    if (!ensure_w(st.wide, (size_t)st.n_pairs * kWideStrideF4 * sizeof(float4), err)) return false;
+    if (!ensure_w(st.wide, (size_t)st.n_pairs * (kWideStrideF4 * sizeof(float4) + 32), err)) return false;      // nodes, then 32 bytes of links per node
+    st.wide_cap = st.n_pairs;
+    uint4 *links = (uint4 *)((float4 *)st.wide.ptr + (size_t)kWideStrideF4 * st.wide_cap);
     if (!ensure_w(st.wide_queue[0], (size_t)st.n_pairs * 8, err) || !ensure_w(st.wide_queue[1], (size_t)st.n_pairs * 8, err)) return false;
     if (!ensure_w(st.wide_levels_dev, (kWideMaxLevels + 3) * 4, err)) return false;
     uint32_t *lc = (uint32_t *)st.wide_levels_dev.ptr;
@@ -431,7 +433,7 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
     hipLaunchKernelGGL(k_wide_init, dim3(1), dim3(128), 0, stream, lc, kWideMaxLevels + 1, (uint2 *)st.wide_queue[0].ptr);
     uint32_t *first_level = lc + kWideMaxLevels + 2;
     hipLaunchKernelGGL(k_wide_top, dim3(1), dim3(kWideTopThreads), 0, stream, (const float4 *)st.pairs.ptr, choice, lc, kWideMaxLevels, first_level,
-                       (uint2 *)st.wide_queue[0].ptr, (uint2 *)st.wide_queue[1].ptr, (float4 *)st.wide.ptr, kWideStrideF4);
+                       (uint2 *)st.wide_queue[0].ptr, (uint2 *)st.wide_queue[1].ptr, (float4 *)st.wide.ptr, links);
     const uint32_t grid = std::min<uint32_t>(2048u, (st.n_pairs + 127u) / 128u);
     uint32_t host_lc[kWideMaxLevels + 3];
     uint32_t level = 1;      // k_wide_top always does level 0 (one node)
@@ -440,7 +442,7 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
         for (; level < chunk_end; level++)
             hipLaunchKernelGGL(k_wide_level, dim3(grid), dim3(128), 0, stream, (const float4 *)st.pairs.ptr, choice, level, lc, (const uint32_t *)first_level,
                                (const uint2 *)st.wide_queue[level & 1].ptr, (uint2 *)st.wide_queue[(level & 1) ^ 1].ptr,
-                               (float4 *)st.wide.ptr, kWideStrideF4);
+                               (float4 *)st.wide.ptr, links);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(host_lc, lc, (kWideMaxLevels + 3) * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));

@@ -105,6 +105,7 @@ DeviceSceneHost scene_view(const crt_context *ctx) {
     DeviceSceneHost s{};
     s.nodes = ctx->build.pairs.ptr; s.n_pairs = ctx->build.n_pairs;
     s.wide = ctx->build.n_wide ? ctx->build.wide.ptr : nullptr; s.n_wide = ctx->build.n_wide; s.wide_levels = ctx->build.wide_levels;
+    s.wide_links = ctx->build.n_wide ? (const uint32_t *)((const float4 *)ctx->build.wide.ptr + (size_t)kWideStrideF4 * ctx->build.wide_cap) : nullptr;
     s.tri_pack = ctx->build.tri_pack.ptr; s.sphere_pack = ctx->build.sphere_pack.ptr; s.quad_pack = ctx->build.quad_pack.ptr;
     s.tri_shade = ctx->build.tri_shade.ptr;
     s.sphere_ids = (const uint32_t *)ctx->build.sphere_ids.ptr; s.quad_ids = (const uint32_t *)ctx->build.quad_ids.ptr;
@@ -716,7 +717,20 @@ int crt_bvh_wide_read(crt_context *ctx, void *nodes, uint32_t *n_nodes, uint32_t
     *n_nodes = ctx->build.n_wide;
     if (n_levels) *n_levels = ctx->build.wide_levels;
     CTX_HIP(hipStreamSynchronize(ctx->stream));
-    if (nodes && ctx->build.n_wide) CTX_HIP(hipMemcpy(nodes, ctx->build.wide.ptr, (size_t)ctx->build.n_wide * kWideStrideF4 * 16, hipMemcpyDeviceToHost));
+    if (nodes && ctx->build.n_wide) {
+        // The caller's view stays one 128-byte record per node (64 bytes of node, 32 of links, 32 unused); on the device
+        // the links live apart from the nodes.
+        const size_t n = ctx->build.n_wide;
+        std::vector<uint8_t> hot(n * 64), links(n * 32);
+        CTX_HIP(hipMemcpy(hot.data(), ctx->build.wide.ptr, n * 64, hipMemcpyDeviceToHost));
+        CTX_HIP(hipMemcpy(links.data(), (const uint8_t *)ctx->build.wide.ptr + (size_t)kWideStrideF4 * 16 * ctx->build.wide_cap, n * 32, hipMemcpyDeviceToHost));
+        uint8_t *out = (uint8_t *)nodes;
+        for (size_t i = 0; i < n; i++) {
+            memcpy(out + 128 * i, hot.data() + 64 * i, 64);
+            memcpy(out + 128 * i + 64, links.data() + 32 * i, 32);
+            memset(out + 128 * i + 96, 0, 32);
+        }
+    }
     return CRT_OK;
 }
 

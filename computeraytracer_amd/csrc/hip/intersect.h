@@ -16,6 +16,7 @@ struct DeviceScene {
     const float4 *nodes;        // pair p = nodes[4p .. 4p+3] = {lo0|link0, hi0|count0, lo1|link1, hi1|count1}
     uint32_t n_pairs;           // 0 = empty scene
     const float4 *wide;         // 8-wide quantised nodes (bvh_wide.hip), null unless built with CRT_BVH_WIDE
+    const uint32_t *wide_links; // their leaf links, eight words per node
     uint32_t n_wide;
     const float4 *tri_pack;     // sorted slot s: {v0.xyz, e10.x} {e10.y, e10.z, e20.x, e20.y} {e20.z, id bits, -, -}
     const float4 *sphere_pack;  // sorted slot s: {center.xyz, radius}

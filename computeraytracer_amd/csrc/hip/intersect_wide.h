@@ -24,7 +24,7 @@ namespace crt {
 #endif
 constexpr int kWideLds = CRT_WIDE_LDS_STACK;          // 8-byte entries per lane in LDS; deeper levels spill to scratch
 constexpr int kWideSpill = 64;                        // the build refuses trees deeper than 64 levels (lds_depth may be as low as 1)
-constexpr uint32_t kWideNodeF4 = 8;                   // = kWideStrideF4 (build_internal.h)
+constexpr uint32_t kWideNodeF4 = 4;                   // = kWideStrideF4 (build_internal.h)
 constexpr uint32_t kEmptyLeaf = kLeafTag | (3u << 29);
 
 struct WideTrav {
@@ -63,7 +63,7 @@ CRT_DEV void wide_order_table(uint8_t *order, uint32_t tid, uint32_t n_threads) 
 }
 
 template <bool SPILL>
-CRT_DEV bool wide_advance(const float4 *nodes, const uint8_t *order, WideTrav &tr, const uint2 *stack, uint32_t stack_stride, const uint2 *spill, int lds_depth) {
+CRT_DEV bool wide_advance(const uint32_t *links, const uint8_t *order, WideTrav &tr, const uint2 *stack, uint32_t stack_stride, const uint2 *spill, int lds_depth) {
     if ((tr.g_pend & 0xFFu) == 0u) {
         if (tr.sp == 0) return false;
         tr.sp--;
@@ -76,7 +76,7 @@ CRT_DEV bool wide_advance(const float4 *nodes, const uint8_t *order, WideTrav &t
     const uint32_t bit = 1u << slot, imask = tr.g_hdr & 0xFFu;
     tr.g_pend ^= bit;
     if (imask & bit) tr.cur = (tr.g_hdr >> 8) + (uint32_t)__builtin_popcount(imask & (bit - 1u));
-    else tr.cur = ((const uint32_t *)nodes)[(size_t)(tr.g_pend >> 8) * (kWideNodeF4 * 4u) + 16u + slot];
+    else tr.cur = links[(size_t)(tr.g_pend >> 8) * 8u + slot];
     return true;
 }
 
@@ -145,9 +145,9 @@ CRT_DEV void wide_visit(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_
 
 // Inner step: tr.cur is a node index.
 template <bool COUNT, bool SPILL>
-CRT_DEV bool wide_inner(const float4 *nodes, const uint8_t *order, WideTrav &tr, uint2 *stack, uint32_t stack_stride, uint2 *spill, int lds_depth, Counts &cnt) {
+CRT_DEV bool wide_inner(const float4 *nodes, const uint32_t *links, const uint8_t *order, WideTrav &tr, uint2 *stack, uint32_t stack_stride, uint2 *spill, int lds_depth, Counts &cnt) {
     wide_visit<COUNT, SPILL>(nodes, tr, stack, stack_stride, spill, lds_depth, cnt);
-    return wide_advance<SPILL>(nodes, order, tr, stack, stack_stride, spill, lds_depth);
+    return wide_advance<SPILL>(links, order, tr, stack, stack_stride, spill, lds_depth);
 }
 
 // Leaf step: tr.cur is a tagged leaf entry.
@@ -159,7 +159,7 @@ CRT_DEV bool wide_leaf(const DeviceScene &sc, const uint8_t *order, WideTrav &tr
         test_leaf<COUNT, EXT>(sc, tr.o, tr.d, first, (kind << 28) | n, tr.best_t, tr.best_id, cnt);
         tr.tfar = tr.best_t * 1.000004f;                // relative pad (2^-18) on the far bound
     }
-    return wide_advance<SPILL>(sc.wide, order, tr, stack, stack_stride, spill, lds_depth);
+    return wide_advance<SPILL>(sc.wide_links, order, tr, stack, stack_stride, spill, lds_depth);
 }
 
 }  // namespace crt

@@ -35,7 +35,7 @@ constexpr uint32_t kBatchMax = 64;
 static DeviceScene to_device_scene(const DeviceSceneHost &h) {
     DeviceScene d;
     d.nodes = (const float4 *)h.nodes; d.n_pairs = h.n_pairs;
-    d.wide = (const float4 *)h.wide; d.n_wide = h.n_wide;
+    d.wide = (const float4 *)h.wide; d.wide_links = h.wide_links; d.n_wide = h.n_wide;
     d.tri_pack = (const float4 *)h.tri_pack; d.sphere_pack = (const float4 *)h.sphere_pack; d.quad_pack = (const float4 *)h.quad_pack;
     d.tri_shade = (const float4 *)h.tri_shade;
     d.sphere_ids = h.sphere_ids; d.quad_ids = h.quad_ids;
@@ -285,7 +285,7 @@ template <bool SPILL> struct LaneTrav<true, SPILL> {           // 8-wide quantis
     WideTrav tr;
     CRT_DEV void begin(V3 o, V3 d) { wide_begin(tr, o, d); }
     CRT_DEV bool at_leaf() const { return (tr.cur & kLeafTag) != 0; }
-    template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, const uint8_t *order, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_inner<COUNT, SPILL>(sc.wide, order, tr, stack, 256, spill, depth, c); }
+    template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, const uint8_t *order, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_inner<COUNT, SPILL>(sc.wide, sc.wide_links, order, tr, stack, 256, spill, depth, c); }
     template <bool COUNT, bool EXT> CRT_DEV bool leaf(const DeviceScene &sc, const uint8_t *order, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_leaf<COUNT, SPILL, EXT>(sc, order, tr, stack, 256, spill, depth, c); }
 };
 static_assert(kLdsStack * 4 == kWideLds * 8, "both stack layouts use the same LDS block");
