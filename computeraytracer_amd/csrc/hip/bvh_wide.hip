@@ -6,7 +6,9 @@
 // costs four for eight.  The tree also shrinks from 64 B per primitive to ~25 B, most of it resident in the
 // 4 MiB L2 of each XCD.
 //
-// Node (128-byte stride, the first 64 bytes are what a traversal step loads):
+// Node (64 bytes on the device = what a traversal step loads, two siblings per 128-byte cache line; the links are a separate
+// array of 32 bytes per node behind the nodes; crt_bvh_wide_read hands both out as one 128-byte record per node, laid out
+// as listed here):
 //   float4 0   {ox|ex, oy|ey, oz|ez, child_base<<8 | imask}
 //              o* = node origin as an fp32 with the low 9 mantissa bits cleared (rounded DOWN), e* = biased exponent
 //              of the per-axis grid step (2^(e-127)) in those low 8 bits; child_base = index of the first inner child
@@ -17,7 +19,7 @@
 //   float4 4,5 link[8]: leaf slot = kLeafTag | kind << 29 | (count - 1) << 26 | first slot in the kind's array
 //              (loaded lazily, only when a leaf slot is actually hit); inner slot = its node index (diagnostic);
 //              empty slot = kLeafTag | 3 << 29
-//   float4 6,7 unused
+//   float4 6,7 unused (read-back record only)
 // Child box of slot s on axis a = [o_a + qlo * 2^e_a, o_a + qhi * 2^e_a] as REAL numbers; it contains the child's box of
 // the pair BVH by construction (wide_emit rounds outwards with 2^-10 of a grid step of slack against its own single
 // rounding; tests/test_gpu_parity.py::_check_wide verifies the containment exactly).  Empty slots have qlo = 255,

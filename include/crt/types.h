@@ -197,7 +197,7 @@ enum {
     CRT_BVH_LEAF_COLLAPSE = 1u << 1, /* LBVH only: keep the Morton topology but close subtrees as multi-primitive leaves
                                       where the SAH prefers it (bottom-up, during the refit) */
     CRT_BVH_WIDE = 1u << 2          /* + collapse the pair BVH into 8-wide nodes with 8-bit quantised child boxes
-                                      (128-byte stride, 64 bytes loaded per visit); the wavefront tracer walks these,
+                                      (64 bytes per node, loaded whole per visit, leaf links in a separate array); the wavefront tracer walks these,
                                       the megakernel and crt_bvh_read keep using the pair BVH */
 };
 
