@@ -319,7 +319,9 @@ int crt_scene_upload(crt_context *ctx, const crt_scene_desc *s) {
     if (s->n_textures) {
         // The shader samples textures[0] only (compute.comp:386-387); the others are resident behind it, in one allocation,
         // for CRT_EXT_TEXTURE_INDEX.  tex_table[i] = {first texel, width, height, 0}.
-        std::vector<uint32_t> table(4 * (size_t)s->n_textures);
+        std::vector<uint32_t> table;
+        try { table.resize(4 * (size_t)s->n_textures); }
+        catch (const std::bad_alloc &) { return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload: out of host memory for the texture table"); }
         size_t texels = 0;
         for (uint32_t i = 0; i < s->n_textures; i++) {
             const crt_texture &t = s->textures[i];
@@ -721,7 +723,9 @@ int crt_bvh_wide_read(crt_context *ctx, void *nodes, uint32_t *n_nodes, uint32_t
         // The caller's view stays one 128-byte record per node (64 bytes of node, 32 of links, 32 unused); on the device
         // the links live apart from the nodes.
         const size_t n = ctx->build.n_wide;
-        std::vector<uint8_t> hot(n * 64), links(n * 32);
+        std::vector<uint8_t> hot, links;
+        try { hot.resize(n * 64); links.resize(n * 32); }      // nothing may leave an extern "C" function as an exception
+        catch (const std::bad_alloc &) { return fail(ctx, CRT_ERR_HIP, "crt_bvh_wide_read: out of host memory"); }
         CTX_HIP(hipMemcpy(hot.data(), ctx->build.wide.ptr, n * 64, hipMemcpyDeviceToHost));
         CTX_HIP(hipMemcpy(links.data(), (const uint8_t *)ctx->build.wide.ptr + (size_t)kWideStrideF4 * 16 * ctx->build.wide_cap, n * 32, hipMemcpyDeviceToHost));
         uint8_t *out = (uint8_t *)nodes;
