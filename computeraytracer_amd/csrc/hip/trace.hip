@@ -248,7 +248,9 @@ __global__ __launch_bounds__(256) void k_wf_generate(DeviceScene sc, Frame f, Wf
     const uint64_t rs = rng.pack();
     q.ray_o[0][slot] = make_float4(o.x, o.y, o.z, u2f((uint32_t)rs));
     q.ray_d[0][slot] = make_float4(d.x, d.y, d.z, u2f((it << kPixBits) | (prow * f.width + x)));
-    q.thr[0][slot] = make_float4(1.0f, 1.0f, 1.0f, u2f((uint32_t)(rs >> 32)));
+    // the throughput of a primary ray is (1, 1, 1) and the hash RNG's state has no high word: k_wf_shade does not read
+    // this array at bounce 0 then (16 of the 48 bytes per path this kernel would write, 16 of the 56 that one would read)
+    if (RNGM != 0) q.thr[0][slot] = make_float4(1.0f, 1.0f, 1.0f, u2f((uint32_t)(rs >> 32)));
 }
 
 // Home sub-queue of a wave: blocks b and b + 8 share an XCD (and its L2), so the waves of one XCD start on
@@ -462,7 +464,9 @@ __global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene s
         if (live) {
             pix = f2u(d4.w);
             {
-                float4 o4 = q.ray_o[in][slot], c4 = q.thr[in][slot];
+                const float4 o4 = q.ray_o[in][slot];
+                float4 c4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);      // what k_wf_generate would have stored
+                if (RNGM != 0 || bounce != 0) c4 = q.thr[in][slot];
                 o = mk3(o4.x, o4.y, o4.z); d = mk3(d4.x, d4.y, d4.z);
                 color = mk3(c4.x, c4.y, c4.z);
                 V3 emitted = mk3(0.0f, 0.0f, 0.0f);      // see the queue-entry comment
