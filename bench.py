@@ -224,8 +224,8 @@ def main():
     ap.add_argument("--tracer", default=os.environ.get("CRT_TRACER", "wavefront"), choices=["megakernel", "wavefront"])
     ap.add_argument("--spp-per-step", type=int, default=16, help="iterations (samples per pixel) per step; static-scene workloads only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bvh", default=os.environ.get("CRT_BVH", ""), choices=["", "lbvh", "sah", "collapse", "lbvh-wide", "sah-wide"],
-                    help="default: sah-wide (static scenes), lbvh-wide for the per-frame rebuild workload")
+    ap.add_argument("--bvh", default=os.environ.get("CRT_BVH", ""), choices=["", "lbvh", "sah", "collapse", "lbvh-wide", "sah-wide", "direct"],
+                    help="default: sah-wide (static scenes), direct (CRT_BVH_WIDE_DIRECT) for the per-frame rebuild workload")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -263,13 +263,13 @@ def main():
     tracer = abi.TRACER_WAVEFRONT if args.tracer == "wavefront" else abi.TRACER_MEGAKERNEL
     rebuild = args.workload == "grid10m_1080p"
     if not args.bvh:
-        args.bvh = "lbvh-wide" if rebuild else "sah-wide"
+        args.bvh = "direct" if rebuild else "sah-wide"
 
     ctx = abi.Context(local_rank)
     ctx.configure(W, H, tracer=tracer, band_rank=rank, band_world=world)
     ctx.upload(scene)
     bvh_flags = {"lbvh": abi.BVH_LBVH, "sah": abi.BVH_SAH_REFINE, "collapse": abi.BVH_LEAF_COLLAPSE,
-                 "lbvh-wide": abi.BVH_LBVH | abi.BVH_WIDE, "sah-wide": abi.BVH_SAH_REFINE | abi.BVH_WIDE}[args.bvh]
+                 "lbvh-wide": abi.BVH_LBVH | abi.BVH_WIDE, "sah-wide": abi.BVH_SAH_REFINE | abi.BVH_WIDE, "direct": abi.BVH_WIDE_DIRECT}[args.bvh]
     wide = args.bvh.endswith("-wide") and tracer == abi.TRACER_WAVEFRONT
     build_ms = ctx.build(bvh_flags)
     build_ms = ctx.build(bvh_flags)   # second build: allocations are warm, this is the device time of the build alone

@@ -38,6 +38,7 @@ struct BuildState {
     DeviceBuffer refit_list[2], refit_count[2];      // parked climbers between the stages of the LBVH refit
     uint32_t n_wide = 0, wide_levels = 0;
     uint32_t pair_depth = 0;                         // levels of the SAH-refined pair tree (0: not measured, LBVH <= 95)
+    bool pairs_valid = false;                        // false after a CRT_BVH_WIDE_DIRECT build: no pair tree, only the 8-wide one
     bool levels_measured = false;                    // level_hist / dp_depth describe the current pairs (bvh_sah.hip: measure_pair_depths)
     uint32_t level_hist[128] = {};                   // pairs per depth (root = 1)
 };
@@ -45,6 +46,8 @@ struct BuildState {
 constexpr uint32_t kWideStrideF4 = 4;     // 64-byte nodes (what a step loads): two siblings per 128-byte line; the eight links of node i
                                           // live apart, at 32 bytes per node, behind the node array (build_wide / wide_links_of)
 constexpr uint32_t kWideMaxLevels = 64;
+constexpr uint32_t kWideLeafTag = 0x80000000u;                  // link word of a leaf slot: tag | kind << 29 | (count - 1) << 26 | first slot in the kind's array
+constexpr uint32_t kWideEmptyLink = kWideLeafTag | (3u << 29);  // ... of an empty slot
 constexpr uint32_t kPairLevels = 128;      // bins of the depth histogram (> kMaxPairDepth)
 constexpr uint32_t kMaxPairDepth = 96;    // pair trees deeper than this are refused: a walk pushes at most depth - 1 entries and the
                                           // stacks hold at least 1 (LDS, debug minimum) + 96 (scratch), intersect.h
@@ -54,6 +57,9 @@ bool build_sah(hipStream_t stream, const BuildInput &in, BuildState &st, const u
 bool patch_sah_links(hipStream_t stream, BuildState &st, std::string &err);
 bool measure_pair_depths(hipStream_t stream, BuildState &st, std::string &err);
 bool build_wide(hipStream_t stream, BuildState &st, std::string &err);
+struct PackOut;
+bool build_wide_direct(hipStream_t stream, const BuildInput &in, BuildState &st, const uint64_t *keys, uint32_t idx_bits, const uint32_t *rank_sphere,
+                       const uint32_t *rank_quad, const PackOut &out, std::string &err);
 bool animate_tris(hipStream_t stream, uint32_t n, const crt_tri *rest, crt_tri *out, float frame, float amplitude, std::string &err);
 void free_build_state(BuildState &st);
 

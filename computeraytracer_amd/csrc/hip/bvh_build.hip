@@ -26,45 +26,13 @@
 
 #include "build_internal.h"
 #include "bvh_common.h"
+#include "bvh_pack.h"
 
 namespace crt {
 
 __global__ void k_init_bounds(uint32_t *b) {
     if (threadIdx.x < 3) b[threadIdx.x] = 0xFFFFFFFFu;       // min
     else if (threadIdx.x < 6) b[threadIdx.x] = 0u;           // max
-}
-
-// Conservative padding: the slab test runs in fma form with rounded -o/d terms (intersect.h); 2^-18
-// of the coordinate magnitude is ~64 ulp, far above its error, far below any feature size.
-__device__ __forceinline__ void pad_box(float lo[3], float hi[3]) {
-    for (int a = 0; a < 3; a++) {
-        float m = fmaxf(fabsf(lo[a]), fabsf(hi[a]));
-        float p = m * 3.8146973e-6f + (hi[a] - lo[a]) * 9.5367432e-7f + 1e-30f;
-        lo[a] -= p; hi[a] += p;
-    }
-}
-
-__device__ __forceinline__ void prim_box(const BuildInput &in, uint32_t g, float lo[3], float hi[3]) {
-    if (g < in.n_spheres) {
-        const crt_sphere &s = in.spheres[g];
-        float r = fabsf(s.radius);
-        for (int a = 0; a < 3; a++) { lo[a] = s.center[a] - r; hi[a] = s.center[a] + r; }
-    } else if (g < in.n_spheres + in.n_quads) {
-        const crt_quad &q = in.quads[g - in.n_spheres];
-        for (int a = 0; a < 3; a++) {
-            float c = q.corner[a], cu = c + q.u[a], cv = c + q.v[a], cuv = (c + q.u[a]) + q.v[a];
-            lo[a] = fminf(fminf(c, cu), fminf(cv, cuv));
-            hi[a] = fmaxf(fmaxf(c, cu), fmaxf(cv, cuv));
-        }
-    } else {
-        // three 16-byte loads (v0, v1, v2 rows of the 96-byte record) instead of nine strided dwords
-        const float4 *p = (const float4 *)(in.tris + (g - in.n_spheres - in.n_quads));
-        const float4 v0 = p[0], v1 = p[1], v2 = p[2];
-        lo[0] = fminf(fminf(v0.x, v1.x), v2.x); hi[0] = fmaxf(fmaxf(v0.x, v1.x), v2.x);
-        lo[1] = fminf(fminf(v0.y, v1.y), v2.y); hi[1] = fmaxf(fmaxf(v0.y, v1.y), v2.y);
-        lo[2] = fminf(fminf(v0.z, v1.z), v2.z); hi[2] = fmaxf(fmaxf(v0.z, v1.z), v2.z);
-    }
-    pad_box(lo, hi);
 }
 
 // Shading record of triangle i (input order, 64 bytes = half a cache line, never straddling one): everything k_wf_shade
@@ -83,6 +51,9 @@ __device__ __forceinline__ void write_tri_shade(const BuildInput &in, uint32_t g
     o[3] = make_float4(tu.z, tv.x, tv.y, tv.z);
 }
 
+// BOXES = false (CRT_BVH_WIDE_DIRECT, which takes the boxes from the shading records later): only the centroid is kept,
+// in plo: 16 instead of 32 bytes written here and read by k_morton.
+template <bool BOXES>
 __global__ __launch_bounds__(256) void k_prim_bounds(BuildInput in, uint32_t n, float4 *plo, float4 *phi, float4 *tri_shade, uint32_t *scene_bounds) {
     // grid-stride: the grid is capped (build_bvh) so that the atomics below stay a few thousand however large n is
     uint32_t cmn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, cmx[3] = {0u, 0u, 0u};
@@ -90,8 +61,10 @@ __global__ __launch_bounds__(256) void k_prim_bounds(BuildInput in, uint32_t n, 
         float lo[3], hi[3];
         prim_box(in, g, lo, hi);
         if (g >= in.n_spheres + in.n_quads) write_tri_shade(in, g, tri_shade);
-        plo[g] = make_float4(lo[0], lo[1], lo[2], 0.0f);
-        phi[g] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+        if (BOXES) {
+            plo[g] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+            phi[g] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+        } else plo[g] = make_float4(0.5f * lo[0] + 0.5f * hi[0], 0.5f * lo[1] + 0.5f * hi[1], 0.5f * lo[2] + 0.5f * hi[2], 0.0f);
         for (int a = 0; a < 3; a++) { const uint32_t e = enc_f(0.5f * lo[a] + 0.5f * hi[a]); cmn[a] = min(cmn[a], e); cmx[a] = max(cmx[a], e); }
     }
     // block-level min/max of the centroids (wave shuffles, then LDS), one atomic per block and axis: the six result
@@ -134,8 +107,11 @@ __global__ void k_morton(uint32_t n, uint32_t bits, uint32_t idx_bits, const flo
                          const uint32_t *scene_bounds, uint64_t *keys, uint32_t *vals) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
-    float4 lo = plo[g], hi = phi[g];
-    float c[3] = {0.5f * lo.x + 0.5f * hi.x, 0.5f * lo.y + 0.5f * hi.y, 0.5f * lo.z + 0.5f * hi.z};
+    float c[3];
+    if (phi) {
+        const float4 lo = plo[g], hi = phi[g];
+        c[0] = 0.5f * lo.x + 0.5f * hi.x; c[1] = 0.5f * lo.y + 0.5f * hi.y; c[2] = 0.5f * lo.z + 0.5f * hi.z;
+    } else { const float4 ce = plo[g]; c[0] = ce.x; c[1] = ce.y; c[2] = ce.z; }      // centroids only (k_prim_bounds<false>)
     const float cells = (float)(1u << bits);
     uint64_t q[3];
     // one scale for all axes (cubic Morton cells): normalising each axis by its own extent would spend as many splits
@@ -161,52 +137,13 @@ __global__ void k_kind_flags(uint32_t n, const uint32_t *vals, uint32_t ns, uint
     is_quad[s] = (g >= ns && g < ns + nq) ? 1u : 0u;
 }
 
-// Traversal record of sorted position s (primitive g) into its kind's array; returns the kind and the slot there.
-// WANT_BOX: also the primitive's padded box.  Spheres and quads: prim_box's own arithmetic on the record read here anyway.
-// Triangles: from the record's v0, v0 + e10, v0 + e20, i.e. corners at most an ulp from the uploaded ones, which is far
-// inside the 64-ulp pad and is the triangle the intersection test (which works from v0, e10, e20) sees.
-struct PackOut { float4 *tri_pack, *sphere_pack, *quad_pack; uint32_t *sphere_ids, *quad_ids, *tri_ids; };
-template <bool WANT_BOX>
-__device__ __forceinline__ void pack_prim(const BuildInput &in, uint32_t n, uint32_t s, uint32_t g, const uint32_t *rank_sphere, const uint32_t *rank_quad,
-                                          const float4 *tri_shade, const PackOut &out, uint32_t &kind, uint32_t &slot, float lo[3], float hi[3]) {
-    // rank arrays are null when the scene holds one kind of primitive: every sorted position is that kind's slot
-    uint32_t rs = rank_sphere ? rank_sphere[s] : (in.n_spheres == n ? s : 0u), rq = rank_quad ? rank_quad[s] : (in.n_quads == n ? s : 0u);
-    if (g < in.n_spheres) {
-        const crt_sphere &sp = in.spheres[g];
-        out.sphere_pack[rs] = make_float4(sp.center[0], sp.center[1], sp.center[2], sp.radius);
-        out.sphere_ids[rs] = g;
-        kind = CRT_ID_KIND_SPHERE; slot = rs;
-    } else if (g < in.n_spheres + in.n_quads) {
-        uint32_t i = g - in.n_spheres;
-        const crt_quad &q = in.quads[i];
-        float4 *o = out.quad_pack + 4 * (size_t)rq;
-        o[0] = make_float4(q.normal[0], q.normal[1], q.normal[2], q.d);
-        o[1] = make_float4(q.corner[0], q.corner[1], q.corner[2], q.u[0]);
-        o[2] = make_float4(q.u[1], q.u[2], q.v[0], q.v[1]);
-        o[3] = make_float4(q.v[2], q.w[0], q.w[1], q.w[2]);
-        out.quad_ids[rq] = i;
-        kind = CRT_ID_KIND_QUAD; slot = rq;
-    } else {
-        uint32_t i = g - in.n_spheres - in.n_quads;
-        uint32_t rt = s - rs - rq;
-        // v0, e10 = v1 - v0, e20 = v2 - v0 (the two IEEE subtractions of hit_tri, compute.comp:281-282) are the head of
-        // the triangle's 64-byte shading record, written by k_prim_bounds: half a cache line instead of a 96-byte upload record
-        const float4 *tp = tri_shade + 4 * (size_t)i;
-        const float4 a = tp[0], b = tp[1], c = tp[2];
-        float4 *o = out.tri_pack + 3 * (size_t)rt;
-        o[0] = a;
-        o[1] = b;
-        o[2] = make_float4(c.x, __uint_as_float(CRT_MAKE_ID(CRT_ID_KIND_TRI, i)), 0.0f, 0.0f);
-        out.tri_ids[rt] = i;
-        kind = CRT_ID_KIND_TRI; slot = rt;
-        if (WANT_BOX) {
-            const float v0[3] = {a.x, a.y, a.z}, v1[3] = {a.x + a.w, a.y + b.x, a.z + b.y}, v2[3] = {a.x + b.z, a.y + b.w, a.z + c.x};
-            for (int k = 0; k < 3; k++) { lo[k] = fminf(fminf(v0[k], v1[k]), v2[k]); hi[k] = fmaxf(fmaxf(v0[k], v1[k]), v2[k]); }
-            pad_box(lo, hi);
-        }
-        return;
-    }
-    if (WANT_BOX) prim_box(in, g, lo, hi);
+// CRT_BVH_WIDE_DIRECT: the sorted primitive index is the low part of the key
+__global__ void k_kind_flags_keys(uint32_t n, const uint64_t *keys, uint32_t idx_mask, uint32_t ns, uint32_t nq, uint32_t *is_sphere, uint32_t *is_quad) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    uint32_t g = (uint32_t)keys[s] & idx_mask;
+    is_sphere[s] = g < ns ? 1u : 0u;
+    is_quad[s] = (g >= ns && g < ns + nq) ? 1u : 0u;
 }
 
 // SAH path (and n == 1): records only; leaf_link[s] = slot inside the kind's array, leaf_count[s] = kind << 28 | 1.
@@ -526,20 +463,29 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     st.n_pairs = n == 0 ? 0 : (n == 1 ? 1 : n - 1);
     st.n_wide = 0; st.wide_levels = 0; st.levels_measured = false; st.pair_depth = 0;
     const bool wide = (flags & CRT_BVH_WIDE) != 0;
+    // CRT_BVH_WIDE_DIRECT (bvh_direct.hip): the 8-wide tree straight from the sorted keys; no pair tree and none of its scratch
+    const bool direct = (flags & CRT_BVH_WIDE_DIRECT) != 0;
+    if (direct && (flags & (CRT_BVH_SAH_REFINE | CRT_BVH_LEAF_COLLAPSE))) { err = "CRT_BVH_WIDE_DIRECT builds from the Morton order alone: not with CRT_BVH_SAH_REFINE / CRT_BVH_LEAF_COLLAPSE"; return false; }
+    st.pairs_valid = !direct;
     if (n == 0) return true;
     const uint32_t blocks = (n + 255) / 256;
     const size_t n4 = (size_t)n * sizeof(float4);
-    if (!ensure(st.plo, n4, err) || !ensure(st.phi, n4, err)) return false;
-    if (!ensure(st.keys, (size_t)n * 8, err) || !ensure(st.vals, (size_t)n * 4, err)) return false;
-    if (!ensure(st.keys_alt, (size_t)n * 8, err) || !ensure(st.vals_alt, (size_t)n * 4, err)) return false;
-    if (!ensure(st.flag_a, (size_t)n * 4, err) || !ensure(st.flag_b, (size_t)n * 4, err)) return false;
-    if (!ensure(st.rank_a, (size_t)n * 4, err) || !ensure(st.rank_b, (size_t)n * 4, err)) return false;
-    if (!ensure(st.leaf_link, (size_t)n * 4, err) || !ensure(st.leaf_count, (size_t)n * 4, err)) return false;
-    if (!ensure(st.child_l, (size_t)n * 4, err) || !ensure(st.child_r, (size_t)n * 4, err)) return false;
-    if (!ensure(st.parent, (size_t)(2 * (size_t)n) * 4, err)) return false;
-    if (!ensure(st.nlo, 2 * n4, err) || !ensure(st.nhi, 2 * n4, err) || !ensure(st.ninfo, 2 * n4, err)) return false;
+    const bool mixed = !(in.n_spheres == n || in.n_quads == n || in.n_tris == n);
+    if (!ensure(st.plo, n4, err) || (!direct && !ensure(st.phi, n4, err))) return false;
+    if (!ensure(st.keys, (size_t)n * 8, err) || !ensure(st.keys_alt, (size_t)n * 8, err)) return false;
+    if (!direct || mixed) {
+        if (!ensure(st.flag_a, (size_t)n * 4, err) || !ensure(st.flag_b, (size_t)n * 4, err)) return false;
+        if (!ensure(st.rank_a, (size_t)n * 4, err) || !ensure(st.rank_b, (size_t)n * 4, err)) return false;
+    }
+    if (!direct) {
+        if (!ensure(st.vals, (size_t)n * 4, err) || !ensure(st.vals_alt, (size_t)n * 4, err)) return false;
+        if (!ensure(st.leaf_link, (size_t)n * 4, err) || !ensure(st.leaf_count, (size_t)n * 4, err)) return false;
+        if (!ensure(st.child_l, (size_t)n * 4, err) || !ensure(st.child_r, (size_t)n * 4, err)) return false;
+        if (!ensure(st.parent, (size_t)(2 * (size_t)n) * 4, err)) return false;
+        if (!ensure(st.nlo, 2 * n4, err) || !ensure(st.nhi, 2 * n4, err) || !ensure(st.ninfo, 2 * n4, err)) return false;
+        if (!ensure(st.pairs, (size_t)st.n_pairs * 4 * sizeof(float4), err)) return false;
+    }
     if (!ensure(st.scene_bounds, 64, err)) return false;
-    if (!ensure(st.pairs, (size_t)st.n_pairs * 4 * sizeof(float4), err)) return false;
     if (!ensure(st.tri_pack, (size_t)in.n_tris * 3 * sizeof(float4), err)) return false;
     if (!ensure(st.sphere_pack, (size_t)in.n_spheres * sizeof(float4), err)) return false;
     if (!ensure(st.quad_pack, (size_t)in.n_quads * 4 * sizeof(float4), err)) return false;
@@ -563,15 +509,16 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     // fit one 64-bit word together (code << idx_bits | index) with no fewer bits per axis than half of log2(n),
     // the sort moves keys only and over the code's bits only: 5 passes of 8 bytes instead of 7 of 12 at 10 M.
     uint32_t idx_bits = 0;
-    if (n > (1u << 20) && !getenv("CRT_BVH_SORT_PAIRS")) {
+    if (direct || (n > (1u << 20) && !getenv("CRT_BVH_SORT_PAIRS"))) {
         uint32_t ib = 1;
         while ((1ull << ib) < (uint64_t)n) ib++;
         const uint32_t fit = std::min(21u, (64u - ib) / 3u);
-        if (fit >= half_log) { idx_bits = ib; bits = std::min(bits, fit); }
+        if (direct || fit >= half_log) { idx_bits = ib; bits = std::min(bits, fit); }      // direct: n < 2^24 leaves 13 bits per axis at least
     }
     const unsigned key_bits = 3 * bits;
     rocprim::double_buffer<uint64_t> dkeys((uint64_t *)st.keys.ptr, (uint64_t *)st.keys_alt.ptr);
     rocprim::double_buffer<uint32_t> dvals((uint32_t *)st.vals.ptr, (uint32_t *)st.vals_alt.ptr);
+    if (direct && n >= (1u << 24)) { err = "wide BVH supports fewer than 2^24 primitives"; return false; }
     if (idx_bits) HIP_TRY(rocprim::radix_sort_keys(nullptr, sort_bytes, dkeys, n, idx_bits, idx_bits + key_bits, stream));
     else HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, dkeys, dvals, n, 0, key_bits, stream));
     HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t *)st.flag_a.ptr, (uint32_t *)st.rank_a.ptr, 0u, n,
@@ -579,15 +526,34 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     if (!ensure(st.temp, std::max(sort_bytes, scan_bytes), err)) return false;
 
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, (uint32_t *)st.scene_bounds.ptr);
-    hipLaunchKernelGGL(k_prim_bounds, dim3(std::min(blocks, 4096u)), dim3(256), 0, stream, in, n, (float4 *)st.plo.ptr, (float4 *)st.phi.ptr,
-                       (float4 *)st.tri_shade.ptr, (uint32_t *)st.scene_bounds.ptr);
+    if (direct) hipLaunchKernelGGL(k_prim_bounds<false>, dim3(std::min(blocks, 4096u)), dim3(256), 0, stream, in, n, (float4 *)st.plo.ptr, (float4 *)nullptr,
+                                   (float4 *)st.tri_shade.ptr, (uint32_t *)st.scene_bounds.ptr);
+    else hipLaunchKernelGGL(k_prim_bounds<true>, dim3(std::min(blocks, 4096u)), dim3(256), 0, stream, in, n, (float4 *)st.plo.ptr, (float4 *)st.phi.ptr,
+                            (float4 *)st.tri_shade.ptr, (uint32_t *)st.scene_bounds.ptr);
     hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, bits, idx_bits, (const float4 *)st.plo.ptr,
-                       (const float4 *)st.phi.ptr, (const uint32_t *)st.scene_bounds.ptr, (uint64_t *)st.keys.ptr, (uint32_t *)st.vals.ptr);
+                       direct ? (const float4 *)nullptr : (const float4 *)st.phi.ptr, (const uint32_t *)st.scene_bounds.ptr, (uint64_t *)st.keys.ptr, (uint32_t *)st.vals.ptr);
     HIP_TRY(hipGetLastError());
     size_t tb = st.temp.bytes;
     if (idx_bits) HIP_TRY(rocprim::radix_sort_keys(st.temp.ptr, tb, dkeys, n, idx_bits, idx_bits + key_bits, stream));
     else HIP_TRY(rocprim::radix_sort_pairs(st.temp.ptr, tb, dkeys, dvals, n, 0, key_bits, stream));
     const uint64_t *keys = dkeys.current(); const uint32_t *vals = dvals.current();
+
+    if (direct) {
+        const uint32_t idx_mask = (uint32_t)((1ull << idx_bits) - 1ull);
+        if (mixed) {
+            hipLaunchKernelGGL(k_kind_flags_keys, dim3(blocks), dim3(256), 0, stream, n, keys, idx_mask, in.n_spheres, in.n_quads,
+                               (uint32_t *)st.flag_a.ptr, (uint32_t *)st.flag_b.ptr);
+            tb = st.temp.bytes;
+            HIP_TRY(rocprim::exclusive_scan(st.temp.ptr, tb, (uint32_t *)st.flag_a.ptr, (uint32_t *)st.rank_a.ptr, 0u, n, rocprim::plus<uint32_t>(), stream));
+            tb = st.temp.bytes;
+            HIP_TRY(rocprim::exclusive_scan(st.temp.ptr, tb, (uint32_t *)st.flag_b.ptr, (uint32_t *)st.rank_b.ptr, 0u, n, rocprim::plus<uint32_t>(), stream));
+        }
+        PackOut pout{(float4 *)st.tri_pack.ptr, (float4 *)st.sphere_pack.ptr, (float4 *)st.quad_pack.ptr, (uint32_t *)st.sphere_ids.ptr,
+                     (uint32_t *)st.quad_ids.ptr, (uint32_t *)st.tri_ids.ptr};
+        st.sorted_vals = nullptr;
+        return build_wide_direct(stream, in, st, keys, idx_bits, mixed ? (const uint32_t *)st.rank_a.ptr : nullptr,
+                                 mixed ? (const uint32_t *)st.rank_b.ptr : nullptr, pout, err);
+    }
 
     // SAH refinement: the Karras hierarchy only clusters; bvh_sah.hip rebuilds the topology and reorders the primitives
     const bool sah = (flags & CRT_BVH_SAH_REFINE) != 0 && n >= 2;
@@ -607,7 +573,6 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
 
     // slot of a sorted position inside its kind's array = number of earlier positions of that kind: two scans, skipped
     // (with the flag kernel) when the scene holds a single kind, as triangle meshes do
-    const bool mixed = !(in.n_spheres == n || in.n_quads == n || in.n_tris == n);
     if (mixed) {
         hipLaunchKernelGGL(k_kind_flags, dim3(blocks), dim3(256), 0, stream, n, order, in.n_spheres, in.n_quads,
                            (uint32_t *)st.flag_a.ptr, (uint32_t *)st.flag_b.ptr);

@@ -1,0 +1,348 @@
+// bvh_direct.hip -- CRT_BVH_WIDE_DIRECT: the 8-wide quantised tree (node format: bvh_wide.hip / intersect_wide.h) built
+// straight from the sorted Morton keys, for the per-frame rebuild of large animated scenes (SURVEY.md section 8(d),
+// config 5).  No binary hierarchy, no refit of a pair tree, no collapse: the pair BVH of the other build modes
+// (640 MB written and read back at 10 M triangles) never exists.
+//
+//   top-down  (k_dw_split, one launch per level): a node is a range of the sorted keys.  It is cut at the highest
+//             differing key bit of its largest part (the LBVH's spatial-median split) until eight parts are there or
+//             every part is a leaf; parts of at most `leaf_max` keys are leaves.  The slot of a part comes from the
+//             sides it took in the cuts (slot bit a = high side of the first cut across axis a), which is the octant
+//             rule the traversal's slot ^ ray-octant order assumes.  Inner parts are numbered in slot order and queued.
+//   bottom-up (k_dw_emit, one launch per level, deepest first): a node packs the traversal records of its leaf
+//             primitives (bvh_pack.h), takes their padded boxes and the exact boxes of its inner children, writes its own
+//             exact box for its parent, quantises the children against it (same arithmetic as wide_emit) and writes
+//             the 64-byte node and its eight links.
+//
+// The keys are code << idx_bits | primitive index (k_morton), unique and sorted by code; parts whose keys differ
+// only in the index bits (equal codes) are cut in the middle.  A root-to-leaf path crosses at most one cut per key bit,
+// so the tree has at most 64 levels (kWideMaxLevels, the traversal's stack bound).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+
+#include "build_internal.h"
+#include "bvh_common.h"
+#include "bvh_pack.h"
+
+namespace crt {
+
+struct DwSplit {
+    const uint64_t *keys; uint32_t idx_bits, leaf_max;
+    uint32_t *level_count;
+    float4 *wide; uint32_t *refs;       // refs: eight words per node in the links array (overwritten by k_dw_emit)
+};
+
+// First position in (b, e) whose key has `bit` set (keys[b] has it clear, keys[e - 1] has it set).  A group of LANES lanes
+// works on one node and probes LANES positions per step: the searches over the millions of keys of a top-level node
+// are chains of dependent loads, 23 deep with one probe per step, 4 deep with 64.
+template <int LANES>
+__device__ __forceinline__ uint32_t dw_find_cut(const uint64_t *keys, uint32_t b, uint32_t e, uint32_t bit, uint32_t gl, uint32_t gbase) {
+    uint32_t lo = b, hi = e - 1u;
+    if (LANES == 1) {
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if ((keys[mid] >> bit) & 1ull) hi = mid; else lo = mid; }
+        return hi;
+    }
+    while (hi - lo > 1u) {
+        const uint32_t step = (hi - lo + (uint32_t)LANES - 1u) / (uint32_t)LANES;
+        const uint32_t p = min(hi, lo + (gl + 1u) * step);                        // the group's last probe is hi itself
+        const bool set = ((keys[p] >> bit) & 1ull) != 0ull;
+        unsigned long long m = __ballot(set) >> gbase;
+        if (LANES < 64) m &= (1ull << LANES) - 1ull;
+        const uint32_t f = (uint32_t)__builtin_ctzll(m);
+        const uint32_t nlo = f ? lo + f * step : lo;                              // probe f - 1 had the bit clear, so it lies below hi
+        hi = min(hi, lo + (f + 1u) * step);
+        lo = nlo;
+    }
+    return hi;
+}
+
+// One node: range -> up to eight parts -> slots, header word, leaf references, queue entries of the inner parts.
+// Every lane of the node's group computes the same values; lane gl == 0 writes.
+template <int LANES>
+__device__ __forceinline__ void dw_split_node(const DwSplit &A, uint32_t level, uint32_t next_base, uint2 range, uint32_t id, uint2 *q_out, uint32_t gl, uint32_t gbase) {
+    uint32_t sb[8], se[8], sd[8];       // part k: keys [sb, se); sd: bits 0..2 side per axis, bits 3..5 "axis was cut"
+#pragma unroll
+    for (int k = 0; k < 8; k++) { sb[k] = 0; se[k] = 0; sd[k] = 0; }
+    sb[0] = range.x; se[0] = range.y;
+    int n = 1;
+    const uint32_t size = range.y - range.x;
+    if (size <= 8u * A.leaf_max) {
+        // Bottom node: every part is a leaf, so where exactly the cuts fall matters little (neighbours in Morton order
+        // share a leaf either way): equal runs of ceil(size / 8) keys, no searches.  The slot of a run comes from the three
+        // key bits of its first key below the range's common prefix (its octant inside the range's cell).
+        const uint32_t c = (size + 7u) / 8u;
+        const uint64_t first = A.keys[range.x], last = A.keys[range.y - 1u];
+        const uint64_t x = first ^ last;
+        const uint32_t bit = x ? 63u - (uint32_t)__clzll((long long)x) : 0u;
+        n = (int)((size + c - 1u) / c);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (k >= n) continue;
+            sb[k] = range.x + (uint32_t)k * c; se[k] = min(range.y, sb[k] + c);
+            const uint64_t fk = A.keys[sb[k]];
+            uint32_t d = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 3; j++) {
+                if (!x || bit < A.idx_bits + j) continue;      // below the code: no spatial meaning
+                const uint32_t bj = bit - j, ax = 2u - (bj - A.idx_bits) % 3u;
+                d |= (8u << ax) | ((uint32_t)((fk >> bj) & 1ull) << ax);
+            }
+            sd[k] = d;
+        }
+    }
+    while (n < 8 && size > 8u * A.leaf_max) {
+        uint32_t best = 0; int bk = -1;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const uint32_t sz = se[k] - sb[k]; if (k < n && sz > A.leaf_max && sz > best) { best = sz; bk = k; } }
+        if (bk < 0) break;
+        uint32_t b = sb[0], e = se[0], d = sd[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++) if (k == bk) { b = sb[k]; e = se[k]; d = sd[k]; }
+        const uint64_t first = A.keys[b], last = A.keys[e - 1];
+        const uint32_t bit = 63u - (uint32_t)__clzll((long long)(first ^ last));      // unique keys: first != last
+        uint32_t m = (b + e) >> 1, dl = d, dr = d;
+        if (bit >= A.idx_bits) {
+            m = dw_find_cut<LANES>(A.keys, b, e, bit, gl, gbase);
+            const uint32_t ax = 2u - (bit - A.idx_bits) % 3u;      // code = ... x y z x y z: bit j of the code belongs to axis 2 - j % 3
+            if (!((d >> (3u + ax)) & 1u)) { dl = d | (8u << ax); dr = dl | (1u << ax); }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (k == bk) { se[k] = m; sd[k] = dl; }
+            if (k == n) { sb[k] = m; se[k] = e; sd[k] = dr; }
+        }
+        n++;
+    }
+    // slots: parts in order, each takes the free slot that disagrees with its known sides on the fewest axes
+    uint32_t slot_of = 0, used = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k >= n) continue;
+        const uint32_t side = sd[k] & 7u, known = sd[k] >> 3;
+        uint32_t bs = 0, bc = 99;
+#pragma unroll
+        for (uint32_t sl = 0; sl < 8; sl++) {
+            const uint32_t c = (uint32_t)__builtin_popcount((sl ^ side) & known) * 8u + (uint32_t)__builtin_popcount((sl ^ side) & 7u);
+            if (!((used >> sl) & 1u) && c < bc) { bc = c; bs = sl; }
+        }
+        slot_of |= bs << (4 * k); used |= 1u << bs;
+    }
+    uint32_t imask = 0, n_inner = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (k < n && se[k] - sb[k] > A.leaf_max) { imask |= 1u << ((slot_of >> (4 * k)) & 7u); n_inner++; }
+    uint32_t qpos = 0;
+    if (n_inner && gl == 0u) qpos = atomicAdd(&A.level_count[level + 1], n_inner);
+    if (LANES > 1) qpos = (uint32_t)__shfl((int)qpos, (int)gbase);
+    const uint32_t child_base = next_base + qpos;
+    uint32_t ref[8];
+#pragma unroll
+    for (int sl = 0; sl < 8; sl++) ref[sl] = kWideEmptyLink;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k >= n) continue;
+        const uint32_t sl = (slot_of >> (4 * k)) & 7u, sz = se[k] - sb[k];
+        uint32_t r;
+        if (sz > A.leaf_max) {
+            const uint32_t rank = (uint32_t)__builtin_popcount(imask & ((1u << sl) - 1u));      // inner children are numbered in slot order
+            if (gl == 0u) q_out[qpos + rank] = make_uint2(sb[k], se[k]);
+            r = child_base + rank;
+        } else r = kWideLeafTag | ((sz - 1u) << 26) | sb[k];      // sorted position of the leaf's first primitive; kind and slot: k_dw_emit
+#pragma unroll
+        for (uint32_t s2 = 0; s2 < 8; s2++) ref[s2] = s2 == sl ? r : ref[s2];
+    }
+    if (gl != 0u) return;
+    uint4 *o = (uint4 *)(A.refs + 8 * (size_t)id);
+    o[0] = make_uint4(ref[0], ref[1], ref[2], ref[3]);
+    o[1] = make_uint4(ref[4], ref[5], ref[6], ref[7]);
+    ((uint32_t *)(A.wide + (size_t)kWideStrideF4 * id))[3] = (child_base << 8) | imask;
+}
+
+// level_count[l] = nodes of level l; level l reads queue l & 1 and appends to the other one.  Node ids are BFS: the
+// nodes of level l are next_base - n_in + [0, n_in).
+__global__ __launch_bounds__(256) void k_dw_split(DwSplit A, uint32_t level, const uint2 *q_in, uint2 *q_out) {
+    const uint32_t n_in = A.level_count[level];
+    uint32_t next_base = 0;
+    for (uint32_t l = 0; l <= level; l++) next_base += A.level_count[l];
+    // A wave per node for the first levels (searches 64 probes wide: 18 instead of 43 us per level at 10 M keys), a lane
+    // per node below: every lane of a group repeats the node's bookkeeping, which from a few thousand nodes on costs more
+    // than the shorter searches save (8 lanes per node at 250 k nodes: 357 instead of 115 us).
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, n_threads = gridDim.x * blockDim.x, lane = threadIdx.x & 63u;
+    if (n_in <= 512u) {
+        for (uint32_t i = tid >> 6; i < n_in; i += n_threads >> 6) dw_split_node<64>(A, level, next_base, q_in[i], next_base - n_in + i, q_out, lane, 0u);
+    } else {
+        for (uint32_t i = tid; i < n_in; i += n_threads) dw_split_node<1>(A, level, next_base, q_in[i], next_base - n_in + i, q_out, 0u, 0u);
+    }
+}
+
+__global__ void k_dw_init(uint32_t *level_count, uint32_t n_levels, uint2 *q0, uint32_t n) {
+    for (uint32_t i = threadIdx.x; i <= n_levels; i += blockDim.x) level_count[i] = i == 0 ? 1u : 0u;
+    if (threadIdx.x == 0) q0[0] = make_uint2(0u, n);
+}
+
+struct DwEmit {
+    const uint64_t *keys; uint32_t idx_mask, n;
+    BuildInput in; const uint32_t *rank_sphere, *rank_quad; const float4 *tri_shade; PackOut out;
+    float4 *wide; uint4 *links; float4 *box;      // box: exact box of node i at [2 i], [2 i + 1]
+};
+
+// Eight lanes per node, one per slot: the leaf primitives of a node are consecutive sorted positions, so a group's
+// gathers and record writes run side by side and coalesce; the node box and the packed plane bytes are reduced over the
+// group with shuffles.
+__device__ __forceinline__ uint32_t or_quad(uint32_t v) {      // OR over the four lanes of a quad
+    v |= (uint32_t)__shfl_xor((int)v, 1); v |= (uint32_t)__shfl_xor((int)v, 2);
+    return v;
+}
+__global__ __launch_bounds__(256) void k_dw_emit(DwEmit A, uint32_t first_id, uint32_t count) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t sl = t & 7u;
+    const bool active = (t >> 3) < count;               // whole groups are active or not
+    const uint32_t id = first_id + (active ? (t >> 3) : 0u);
+    const uint32_t hdr = ((const uint32_t *)(A.wide + (size_t)kWideStrideF4 * id))[3];
+    const uint32_t imask = hdr & 0xFFu, child_base = hdr >> 8;
+    const uint32_t ref = ((const uint32_t *)A.links)[8 * (size_t)id + sl];
+    float clo[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f}, chi[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
+    uint32_t link = ref;
+    bool valid = false;
+    if (active) {
+        if ((imask >> sl) & 1u) {
+            const uint32_t cid = child_base + (uint32_t)__builtin_popcount(imask & ((1u << sl) - 1u));
+            const float4 a = A.box[2 * (size_t)cid], b = A.box[2 * (size_t)cid + 1];
+            clo[0] = a.x; clo[1] = a.y; clo[2] = a.z; chi[0] = b.x; chi[1] = b.y; chi[2] = b.z;
+            valid = true;
+        } else if (ref != kWideEmptyLink) {
+            const uint32_t s0 = ref & ((1u << 26) - 1u), cnt = ((ref >> 26) & 7u) + 1u;
+            uint32_t kind0 = 0, slot0 = 0;
+            for (uint32_t j = 0; j < cnt; j++) {
+                uint32_t kind, slot; float lo[3], hi[3];
+                pack_prim<true>(A.in, A.n, s0 + j, (uint32_t)A.keys[s0 + j] & A.idx_mask, A.rank_sphere, A.rank_quad, A.tri_shade, A.out, kind, slot, lo, hi);
+                if (j == 0) { kind0 = kind; slot0 = slot; }
+#pragma unroll
+                for (int a = 0; a < 3; a++) { clo[a] = fminf(clo[a], lo[a]); chi[a] = fmaxf(chi[a], hi[a]); }
+            }
+            link = kWideLeafTag | (kind0 << 29) | ((cnt - 1u) << 26) | slot0;
+            valid = true;
+        }
+    }
+    // node box over the group (a NaN coordinate of a primitive stays in its own slot's box: fminf / fmaxf drop it here,
+    // and the slot's quantisation below maps it to the full range)
+    float lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float l = clo[a], h = chi[a];
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) { l = fminf(l, __shfl_xor(l, off)); h = fmaxf(h, __shfl_xor(h, off)); }
+        lo[a] = l; hi[a] = h;
+    }
+    const bool any = __builtin_popcount((uint32_t)((__ballot(valid) >> (threadIdx.x & 56u)) & 0xFFull)) != 0;
+    if (!any) { for (int a = 0; a < 3; a++) { lo[a] = 0.0f; hi[a] = 0.0f; } }
+    // origin (rounded down to 15 mantissa bits) and per-axis grid step: wide_emit's arithmetic (bvh_wide.hip)
+    float origin[3], inv_scale[3]; uint32_t ebits[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        uint32_t b = __float_as_uint(lo[a]), tr = b & 0xFFFFFE00u;
+        if ((b & 0x80000000u) && tr != b) tr += 0x200u;          // negative: truncation moved it up, step one unit down
+        origin[a] = __uint_as_float(tr);
+        const float ext = hi[a] - origin[a];
+        int e = -100;
+        if (ext > 0.0f) {
+            int x; const float m = frexpf(ext / 255.0f, &x);
+            e = m > 0.999999f ? x + 1 : x;
+        }
+        if (!(ext <= 3.402823466e38f)) e = 122;
+        e = e < -100 ? -100 : e > 122 ? 122 : e;
+        ebits[a] = (uint32_t)(e + 127);
+        inv_scale[a] = __uint_as_float((uint32_t)(127 - e) << 23);
+    }
+    // this slot's six plane bytes, shifted to their place in the slot's dword; empty slots keep qlo = 255, qhi = 0
+    const uint32_t sh = 8u * (sl & 3u);
+    uint32_t w[6];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float fl = 255.0f, fh = 0.0f;
+        if (valid) {
+            const float xl = (clo[a] - origin[a]) * inv_scale[a], xh = (chi[a] - origin[a]) * inv_scale[a];
+            fl = floorf(xl - 0.0009765625f); fh = ceilf(xh + 0.0009765625f);
+            fl = (fl >= 0.0f && fl <= 255.0f) ? fl : 0.0f;
+            fh = (fh >= 0.0f && fh <= 255.0f) ? fh : 255.0f;
+        }
+        w[a] = (uint32_t)fl << sh; w[3 + a] = (uint32_t)fh << sh;
+    }
+    uint32_t mine[6], other[6];      // the dword of this lane's quad (slots 0-3 or 4-7) and the other quad's
+#pragma unroll
+    for (int k = 0; k < 6; k++) { mine[k] = or_quad(w[k]); other[k] = (uint32_t)__shfl_xor((int)mine[k], 4); }
+    if (!active) return;
+    const bool upper = sl >= 4u;
+    uint32_t q[6][2];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { q[k][0] = upper ? other[k] : mine[k]; q[k][1] = upper ? mine[k] : other[k]; }
+    ((uint32_t *)A.links)[8 * (size_t)id + sl] = link;
+    float4 *o = A.wide + (size_t)kWideStrideF4 * id;
+    if (sl == 0u) {
+        o[0] = make_float4(__uint_as_float(__float_as_uint(origin[0]) | ebits[0]), __uint_as_float(__float_as_uint(origin[1]) | ebits[1]),
+                           __uint_as_float(__float_as_uint(origin[2]) | ebits[2]), __uint_as_float(hdr));
+        A.box[2 * (size_t)id] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+    } else if (sl == 1u) {
+        o[1] = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
+        A.box[2 * (size_t)id + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    } else if (sl == 2u) o[2] = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
+    else if (sl == 3u) o[3] = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
+}
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return false; } } while (0)
+
+static bool ensure_d(DeviceBuffer &b, size_t bytes, std::string &err) {
+    if (b.bytes >= bytes && b.ptr) return true;
+    if (b.ptr) { hipError_t e = hipFree(b.ptr); (void)e; b.ptr = nullptr; b.bytes = 0; }
+    size_t want = bytes < 256 ? 256 : bytes;
+    HIP_TRY(hipMalloc(&b.ptr, want));
+    b.bytes = want;
+    return true;
+}
+
+bool build_wide_direct(hipStream_t stream, const BuildInput &in, BuildState &st, const uint64_t *keys, uint32_t idx_bits, const uint32_t *rank_sphere,
+                       const uint32_t *rank_quad, const PackOut &out, std::string &err) {
+    const uint32_t n = st.n_prims;
+    st.n_wide = 0; st.wide_levels = 0;
+    if (n == 0) return true;
+    if (n >= (1u << 24)) { err = "wide BVH supports fewer than 2^24 primitives"; return false; }
+    // every node has at least two children (or is the root of a scene that is one leaf), so n_pairs = max(n - 1, 1) bounds the node count
+    if (!ensure_d(st.wide, (size_t)st.n_pairs * (kWideStrideF4 * sizeof(float4) + 32), err)) return false;
+    st.wide_cap = st.n_pairs;
+    uint4 *links = (uint4 *)((float4 *)st.wide.ptr + (size_t)kWideStrideF4 * st.wide_cap);
+    if (!ensure_d(st.wide_queue[0], (size_t)st.n_pairs * 8, err) || !ensure_d(st.wide_queue[1], (size_t)st.n_pairs * 8, err)) return false;
+    if (!ensure_d(st.wide_levels_dev, (kWideMaxLevels + 3) * 4, err)) return false;
+    if (!ensure_d(st.nlo, (size_t)st.n_pairs * 2 * sizeof(float4), err)) return false;
+    uint32_t *lc = (uint32_t *)st.wide_levels_dev.ptr;
+    const bool single_kind = in.n_spheres == n || in.n_quads == n || in.n_tris == n;
+    static const uint32_t env_leaf = [] { const char *e = getenv("CRT_DW_LEAF"); int v = e ? atoi(e) : 2; return (uint32_t)(v < 1 ? 1 : v > 8 ? 8 : v); }();
+    DwSplit S{keys, idx_bits, single_kind ? env_leaf : 1u, lc, (float4 *)st.wide.ptr, (uint32_t *)links};
+    hipLaunchKernelGGL(k_dw_init, dim3(1), dim3(128), 0, stream, lc, kWideMaxLevels + 1, (uint2 *)st.wide_queue[0].ptr, n);
+    const uint32_t grid = std::min<uint32_t>(2048u, (st.n_pairs + 255u) / 256u);
+    uint32_t host_lc[kWideMaxLevels + 3];
+    uint32_t level = 0;
+    for (;;) {
+        // blind launches (an empty level costs ~5 us): the depth of a balanced tree plus two the first time, four more after a miss
+        uint32_t expect = 2;
+        for (uint64_t cap = 8ull * S.leaf_max; cap < n; cap *= 8ull) expect++;
+        const uint32_t chunk_end = std::min<uint32_t>(level == 0 ? expect + 1u : level + 4u, kWideMaxLevels);
+        for (; level < chunk_end; level++)
+            hipLaunchKernelGGL(k_dw_split, dim3(grid), dim3(256), 0, stream, S, level, (const uint2 *)st.wide_queue[level & 1].ptr, (uint2 *)st.wide_queue[(level & 1) ^ 1].ptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host_lc, lc, (kWideMaxLevels + 3) * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (host_lc[level] == 0) break;
+        if (level >= kWideMaxLevels) { err = "wide BVH deeper than 64 levels"; return false; }
+    }
+    uint32_t start[kWideMaxLevels + 2];
+    start[0] = 0;
+    for (uint32_t l = 0; l <= kWideMaxLevels && host_lc[l]; l++) { start[l + 1] = start[l] + host_lc[l]; st.n_wide += host_lc[l]; st.wide_levels = l + 1; }
+    DwEmit E{keys, (uint32_t)((1ull << idx_bits) - 1ull), n, in, rank_sphere, rank_quad, (const float4 *)st.tri_shade.ptr, out,
+             (float4 *)st.wide.ptr, links, (float4 *)st.nlo.ptr};
+    for (uint32_t l = st.wide_levels; l-- > 0;)
+        hipLaunchKernelGGL(k_dw_emit, dim3((host_lc[l] + 31u) / 32u), dim3(256), 0, stream, E, start[l], host_lc[l]);
+    HIP_TRY(hipGetLastError());
+    return true;
+}
+
+}  // namespace crt

@@ -51,9 +51,6 @@
 
 namespace crt {
 
-constexpr uint32_t kWideLeafTag = 0x80000000u;
-constexpr uint32_t kWideEmptyLink = kWideLeafTag | (3u << 29);
-
 struct WideChild { float lo[3], hi[3]; uint32_t link, count, budget, eff; };      // eff: the child's eff table (table-driven collapse)
 
 

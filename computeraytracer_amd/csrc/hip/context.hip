@@ -103,7 +103,7 @@ uint32_t local_bands(uint32_t grid_h, uint32_t rank, uint32_t world) {
 
 DeviceSceneHost scene_view(const crt_context *ctx) {
     DeviceSceneHost s{};
-    s.nodes = ctx->build.pairs.ptr; s.n_pairs = ctx->build.n_pairs;
+    s.nodes = ctx->build.pairs_valid ? ctx->build.pairs.ptr : nullptr; s.n_pairs = ctx->build.n_pairs;
     s.wide = ctx->build.n_wide ? ctx->build.wide.ptr : nullptr; s.n_wide = ctx->build.n_wide; s.wide_levels = ctx->build.wide_levels;
     s.wide_links = ctx->build.n_wide ? (const uint32_t *)((const float4 *)ctx->build.wide.ptr + (size_t)kWideStrideF4 * ctx->build.wide_cap) : nullptr;
     s.tri_pack = ctx->build.tri_pack.ptr; s.sphere_pack = ctx->build.sphere_pack.ptr; s.quad_pack = ctx->build.quad_pack.ptr;
@@ -201,6 +201,8 @@ int ready_to_render(crt_context *ctx) {
     if (!ctx->configured) return fail(ctx, CRT_ERR_INVALID, "crt_configure has not been called");
     if (!ctx->have_scene) return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload has not been called");
     if (!ctx->have_bvh) return fail(ctx, CRT_ERR_INVALID, "crt_bvh_build has not been called for the current scene");
+    if (!ctx->build.pairs_valid && ctx->cfg.tracer != CRT_TRACER_WAVEFRONT)
+        return fail(ctx, CRT_ERR_INVALID, "a CRT_BVH_WIDE_DIRECT build has no pair BVH: the megakernel tracer cannot render it (configure CRT_TRACER_WAVEFRONT)");
     return CRT_OK;
 }
 
@@ -692,9 +694,10 @@ int crt_bvh_read(crt_context *ctx, crt_bvh_node *nodes, uint32_t *n_nodes, uint3
     int rc = bind(ctx); if (rc) return rc;
     if (!ctx->have_bvh) return fail(ctx, CRT_ERR_INVALID, "crt_bvh_read: no BVH built");
     if (!n_nodes) return fail(ctx, CRT_ERR_INVALID, "crt_bvh_read: null n_nodes");
-    *n_nodes = ctx->build.n_pairs * 2;
+    const bool pairs = ctx->build.pairs_valid;      // a CRT_BVH_WIDE_DIRECT build has no pair BVH: 0 nodes, the slot IDs are still there
+    *n_nodes = pairs ? ctx->build.n_pairs * 2 : 0;
     CTX_HIP(hipStreamSynchronize(ctx->stream));
-    if (nodes && ctx->build.n_pairs) CTX_HIP(hipMemcpy(nodes, ctx->build.pairs.ptr, (size_t)ctx->build.n_pairs * 64, hipMemcpyDeviceToHost));
+    if (nodes && pairs && ctx->build.n_pairs) CTX_HIP(hipMemcpy(nodes, ctx->build.pairs.ptr, (size_t)ctx->build.n_pairs * 64, hipMemcpyDeviceToHost));
     if (sphere_ids && ctx->n_spheres) CTX_HIP(hipMemcpy(sphere_ids, ctx->build.sphere_ids.ptr, (size_t)ctx->n_spheres * 4, hipMemcpyDeviceToHost));
     if (quad_ids && ctx->n_quads) CTX_HIP(hipMemcpy(quad_ids, ctx->build.quad_ids.ptr, (size_t)ctx->n_quads * 4, hipMemcpyDeviceToHost));
     if (tri_ids && ctx->n_tris) CTX_HIP(hipMemcpy(tri_ids, ctx->build.tri_ids.ptr, (size_t)ctx->n_tris * 4, hipMemcpyDeviceToHost));

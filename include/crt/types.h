@@ -196,9 +196,13 @@ enum {
                                       small same-kind subtrees as multi-primitive leaves */
     CRT_BVH_LEAF_COLLAPSE = 1u << 1, /* LBVH only: keep the Morton topology but close subtrees as multi-primitive leaves
                                       where the SAH prefers it (bottom-up, during the refit) */
-    CRT_BVH_WIDE = 1u << 2          /* + collapse the pair BVH into 8-wide nodes with 8-bit quantised child boxes
+    CRT_BVH_WIDE = 1u << 2,         /* + collapse the pair BVH into 8-wide nodes with 8-bit quantised child boxes
                                       (64 bytes per node, loaded whole per visit, leaf links in a separate array); the wavefront tracer walks these,
                                       the megakernel and crt_bvh_read keep using the pair BVH */
+    CRT_BVH_WIDE_DIRECT = 1u << 3   /* the 8-wide tree built straight from the sorted Morton keys (bvh_direct.hip): the fastest rebuild,
+                                      for per-frame rebuilds of large animated scenes.  No pair BVH exists afterwards: wavefront
+                                      tracer and crt_rays_query only; crt_dispatch / crt_render with the megakernel tracer fail with
+                                      CRT_ERR_INVALID and crt_bvh_read reports 0 nodes (the per-kind slot IDs are still read).  Not with CRT_BVH_SAH_REFINE / CRT_BVH_LEAF_COLLAPSE. */
 };
 
 /* The build's own BVH node (32 B).  Nodes are stored as sibling pairs:

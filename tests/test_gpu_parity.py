@@ -474,14 +474,15 @@ def _edge_scene(kind, w, h):
     return abi.HostScene(spheres=spheres, tris=tris, materials=mats, params=params, name="edge-" + kind)
 
 
-@pytest.mark.parametrize("bvh", [abi.BVH_LBVH, abi.BVH_SAH_REFINE, abi.BVH_LEAF_COLLAPSE, abi.BVH_LBVH | abi.BVH_WIDE, abi.BVH_SAH_REFINE | abi.BVH_WIDE],
-                         ids=["lbvh", "sah", "collapse", "lbvh-wide", "sah-wide"])
+@pytest.mark.parametrize("bvh", [abi.BVH_LBVH, abi.BVH_SAH_REFINE, abi.BVH_LEAF_COLLAPSE, abi.BVH_LBVH | abi.BVH_WIDE, abi.BVH_SAH_REFINE | abi.BVH_WIDE, abi.BVH_WIDE_DIRECT],
+                         ids=["lbvh", "sah", "collapse", "lbvh-wide", "sah-wide", "direct"])
 @pytest.mark.parametrize("kind", ["identical", "degenerate", "far"])
 def test_degenerate_geometry_bit_exact(ctx, kind, bvh):
     w, h = 80, 48
     scene = _edge_scene(kind, w, h)
     ref = None
-    for tracer in (abi.TRACER_MEGAKERNEL, abi.TRACER_WAVEFRONT):
+    tracers = (abi.TRACER_WAVEFRONT,) if bvh & abi.BVH_WIDE_DIRECT else (abi.TRACER_MEGAKERNEL, abi.TRACER_WAVEFRONT)      # no pair BVH for the megakernel there
+    for tracer in tracers:
         img, ids, ps = _gpu_render(ctx, scene, w, h, 2, bvh=bvh, tracer=tracer)
         if ref is None:
             ref = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_BRUTE)
@@ -519,8 +520,8 @@ def _query_rays(scene, n, seed):
     return rays
 
 
-@pytest.mark.parametrize("bvh", [abi.BVH_LBVH, abi.BVH_SAH_REFINE, abi.BVH_LEAF_COLLAPSE, abi.BVH_LBVH | abi.BVH_WIDE, abi.BVH_SAH_REFINE | abi.BVH_WIDE],
-                         ids=["lbvh", "sah", "collapse", "lbvh-wide", "sah-wide"])
+@pytest.mark.parametrize("bvh", [abi.BVH_LBVH, abi.BVH_SAH_REFINE, abi.BVH_LEAF_COLLAPSE, abi.BVH_LBVH | abi.BVH_WIDE, abi.BVH_SAH_REFINE | abi.BVH_WIDE, abi.BVH_WIDE_DIRECT],
+                         ids=["lbvh", "sah", "collapse", "lbvh-wide", "sah-wide", "direct"])
 @pytest.mark.parametrize("name", ["book1", "corne", "cirno", "voxel_city"])
 def test_ray_queries_closest_and_any(ctx, golden_dir, name, bvh):
     """crt_rays_query: closest hits bit-exact (t bits and ID) against the oracle's hit_world, any-hit answers equal to

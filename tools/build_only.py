@@ -7,7 +7,7 @@ from computeraytracer_amd import abi
 import bench
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "lost_empire_4k"
-bvh = {"lbvh": abi.BVH_LBVH, "sah": abi.BVH_SAH_REFINE, "sah-wide": abi.BVH_SAH_REFINE | abi.BVH_WIDE, "lbvh-wide": abi.BVH_WIDE}[sys.argv[2] if len(sys.argv) > 2 else "sah-wide"]
+bvh = {"lbvh": abi.BVH_LBVH, "sah": abi.BVH_SAH_REFINE, "sah-wide": abi.BVH_SAH_REFINE | abi.BVH_WIDE, "lbvh-wide": abi.BVH_WIDE, "direct": abi.BVH_WIDE_DIRECT}[sys.argv[2] if len(sys.argv) > 2 else "sah-wide"]
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 scene_name, W, H, _ = bench.WORKLOADS[wl]
 scene = abi.builtin_scene(scene_name, W, H, os.path.join(ROOT, "tests", "golden"))
