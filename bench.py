@@ -301,7 +301,10 @@ def main():
     run(1, args.warmup)
     ctx.sync()
     ctx.stats_reset()
-    ctx.set_kernel_timing(True)       # HIP events around every k_wf_extend launch, on the stream it is launched on
+    # HIP events around every k_wf_extend launch, on the stream it is launched on.  Not for the per-frame rebuild workload:
+    # per-kernel timing makes every dispatch wait for the previous one and keeps small batches on the per-bounce kernels
+    # (crt_set_kernel_timing, abi.h), and that workload's figure is the frame time
+    ctx.set_kernel_timing(not rebuild)
 
     def barrier():
         if dist is not None:
@@ -384,7 +387,8 @@ def main():
             n_launches = float(st.last_extend_launches) if not rebuild else float(st.last_extend_launches) * args.steps
             launch_ms = st.last_extend_ms / st.last_extend_launches
         else:
-            kernel_name, kernel_bytes_per_ray = "k_megakernel", bytes_per_ray
+            kernel_name = "k_megakernel" if tracer == abi.TRACER_MEGAKERNEL else "k_wf_* (one render call, kernels not timed one by one)"
+            kernel_bytes_per_ray = bytes_per_ray
             n_launches = float(args.steps * spp)
             launch_ms = kernel_ms / (args.steps * spp) if not rebuild else kernel_ms
         launch_rays = rank_rays / n_launches

@@ -19,7 +19,15 @@ struct crt_context {
     hipStream_t stream = nullptr;
     // Two timing slots, like the reference's two frame slots with a fence each (vk_engine.h:18, vk_engine.cpp:1377):
     // dispatch i records into slot i % 2 and only waits if the dispatch two calls back has not finished yet.
-    struct TimingSlot { hipEvent_t start = nullptr, stop = nullptr; bool pending = false; } slot[2];
+    struct TimingSlot { hipEvent_t start = nullptr, stop = nullptr; bool pending = false; int tune_mode = -1; float tune_scale = 1.0f; } slot[2];
+    // Small batches (up to kTailPaths paths: one sample of a 1080p frame) can finish in k_wf_tail, one lane per path through all
+    // its bounces, instead of a k_wf_extend / k_wf_shade pair per bounce.  Which is faster depends on the scene: per-bounce
+    // launches wait for the longest RAY of every bounce, the tail kernel for the longest PATH, which wins where some rays
+    // are very long (10 M-triangle grid seen at grazing angles: 3.1 instead of 4.2 ms a frame) and loses where all
+    // are short (cirno 1080p: 1.6 instead of 1.0 ms).  Same image either way, so the context measures: the first
+    // dispatches alternate, two by two, and after three timed samples of each the faster mode stays until the scene or
+    // the configuration changes.  CRT_WF_TAIL_BOUNCE=n fixes the mode (n < 0: never, else the first bounce of the tail kernel).
+    struct TailTune { int decided = -2; uint32_t calls = 0, samples[2] = {0, 0}; float best[2] = {3.4e38f, 3.4e38f}; } tune;
     uint32_t slot_next = 0;
     hipEvent_t ev_build[2] = {nullptr, nullptr};
     std::string error;
@@ -142,6 +150,13 @@ int harvest_slot(crt_context *ctx, crt_context::TimingSlot &sl, bool block) {
     CTX_HIP(hipEventElapsedTime(&ms, sl.start, sl.stop));
     ctx->last_render_ms = ms;
     sl.pending = false;
+    if (sl.tune_mode >= 0 && ctx->tune.decided == -2) {
+        crt_context::TailTune &t = ctx->tune;
+        t.best[sl.tune_mode] = std::min(t.best[sl.tune_mode], ms / sl.tune_scale);
+        t.samples[sl.tune_mode]++;
+        if (t.samples[0] >= 3 && t.samples[1] >= 3) t.decided = t.best[1] < t.best[0] ? 0 : -1;
+    }
+    sl.tune_mode = -1;
     return CRT_OK;
 }
 
@@ -178,6 +193,25 @@ int begin_timing(crt_context *ctx, crt_context::TimingSlot **out) {
     CTX_HIP(hipEventRecord(sl.start, ctx->stream));
     *out = &sl;
     return CRT_OK;
+}
+
+// Whether the dispatches of this call end in k_wf_tail (crt_context::TailTune); paths = paths of one batch, iters = the
+// iterations the call's time covers.
+void pick_tail(crt_context *ctx, crt_context::TimingSlot *sl, double paths, uint32_t iters) {
+    static const int env_bounce = [] { const char *e = getenv("CRT_WF_TAIL_BOUNCE"); return e ? atoi(e) : -100; }();      // unset: measure
+    static const double max_paths = [] { const char *e = getenv("CRT_WF_TAIL_PATHS"); return e ? atof(e) : 4.2e6; }();
+    ctx->wf.tail_bounce = -1;
+    sl->tune_mode = -1;
+    if (ctx->cfg.tracer != CRT_TRACER_WAVEFRONT || ctx->instrumented || ctx->wf.time_kernels || paths > max_paths || iters == 0) return;
+    if (ctx->cfg.flags & CRT_FLAG_PER_BOUNCE_KERNELS) return;
+    if (ctx->cfg.flags & CRT_FLAG_PATH_KERNEL) { ctx->wf.tail_bounce = 0; return; }
+    if (env_bounce != -100) { ctx->wf.tail_bounce = env_bounce < 0 ? -1 : env_bounce; return; }
+    crt_context::TailTune &t = ctx->tune;
+    if (t.decided != -2) { ctx->wf.tail_bounce = t.decided; return; }
+    const int mode = (int)((t.calls / 2u) & 1u);
+    t.calls++;
+    ctx->wf.tail_bounce = mode ? 0 : -1;
+    sl->tune_mode = mode; sl->tune_scale = (float)iters;
 }
 
 // n_batch > 1 (wavefront tracer only): p.camera.iteration is the first iteration of the batch, seeds[b] its b-th seed.
@@ -287,6 +321,7 @@ int crt_configure(crt_context *ctx, const crt_config *cfg) {
     CTX_HIP(hipMemsetAsync(ctx->hit_ids.ptr, 0xFF, px * 4, ctx->stream));
     CTX_HIP(hipStreamSynchronize(ctx->stream));
     ctx->configured = true;
+    ctx->tune = crt_context::TailTune();
     return CRT_OK;
 }
 
@@ -346,6 +381,7 @@ int crt_scene_upload(crt_context *ctx, const crt_scene_desc *s) {
         ctx->tex0_w = s->textures[0].width; ctx->tex0_h = s->textures[0].height;
     }
     ctx->have_scene = true;
+    ctx->tune = crt_context::TailTune();
     return CRT_OK;
 }
 
@@ -443,6 +479,7 @@ int crt_dispatch(crt_context *ctx, const crt_scene_params *params) {
     if ((rc = ready_to_render(ctx))) return rc;
     crt_context::TimingSlot *sl = nullptr;
     if ((rc = begin_timing(ctx, &sl))) return rc;
+    pick_tail(ctx, sl, (double)ctx->n_local_bands * 8.0 * ctx->grid_w, 1);
     rc = dispatch_one(ctx, *params);
     CTX_HIP(hipEventRecord(sl->stop, ctx->stream));
     sl->pending = true;
@@ -474,6 +511,7 @@ int crt_render(crt_context *ctx, const crt_scene_params *params, uint32_t first_
         if (per_b > 0.0 && batch * per_b > budget) batch = (uint32_t)(budget / per_b) < 1u ? 1u : (uint32_t)(budget / per_b);
         if ((size_t)ctx->local_rows * ctx->cfg.width >= (1u << 26) - 1u) batch = 1;      // ray_d.w packs batch index << 26 | pixel slot
     }
+    pick_tail(ctx, sl, (double)ctx->n_local_bands * 8.0 * ctx->grid_w * (double)(n_iterations < batch ? n_iterations : batch), n_iterations);
     for (uint32_t i = 0; i < n_iterations && rc == CRT_OK; i += batch) {
         const uint32_t nb = n_iterations - i < batch ? n_iterations - i : batch;
         p.camera.iteration = (float)(first_iteration + i);

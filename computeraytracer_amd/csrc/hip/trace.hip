@@ -499,6 +499,66 @@ __global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene s
     }
 }
 
+// The last bounces of a SMALL batch (one sample of a 1080p frame: the reference's own per-frame dispatch, and config 5).
+// From the third bounce on such a batch holds a few hundred thousand paths at most, and a k_wf_extend / k_wf_shade pair
+// per bounce costs its launches plus the latency of its longest ray, ~65 us a bounce with the chip nearly empty.  This
+// kernel takes the survivors of bounce `bounce0` and runs each path to its end, one lane per path: traversal (the same
+// LaneTrav steps, without the wave-level phases) and shade_hit in a loop, no queue traffic in between.  Same functions,
+// same order of RNG draws per path as the per-bounce kernels: the image is bit-identical.
+template <int RNGM, bool WIDE, bool SPILL, bool EXT>
+__global__ __launch_bounds__(256) void k_wf_tail(DeviceScene sc, Frame f, WfQueues q, uint32_t bounce0, unsigned long long dead, float4 *pass_buf, uint32_t pass_stride, uint32_t *hit_ids, DeviceStats *stats) {
+    __shared__ uint2 s_stack[kWideLds * 256];
+    __shared__ uint8_t s_order[WIDE ? kWideOrderBytes : 4];
+    if (WIDE) { wide_order_table(s_order, threadIdx.x, blockDim.x); __syncthreads(); }
+    if (bounce0 == 0 && blockIdx.x == 0) {      // bounce 0 is counted the way k_wf_extend counts it: queue entries minus ragged-edge lanes (k_wf_generate corrects for the outline view)
+        unsigned long long n = wave_sum(threadIdx.x < kShards ? (unsigned long long)q.counts[threadIdx.x * kCtrStride] : 0ull);
+        if ((threadIdx.x & 63u) == 0u) atomicAdd(&stats->rays, n - (threadIdx.x == 0 ? dead : 0ull));
+    }
+    const uint32_t in = bounce0 & 1;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = t / q.shard_cap, i = t - s * q.shard_cap;
+    unsigned long long rays = 0;
+    if (s < q.n_shards && i < q.counts[(bounce0 * kShards + s) * kCtrStride]) {
+        const uint32_t slot = s * q.shard_cap + i;
+        const float4 o4 = q.ray_o[in][slot], d4 = q.ray_d[in][slot];
+        float4 c4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);      // what k_wf_generate would have stored (see there)
+        if (RNGM != 0 || bounce0 != 0) c4 = q.thr[in][slot];
+        V3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z), color = mk3(c4.x, c4.y, c4.z);
+        uint32_t pix = f2u(d4.w), it = 0;
+        if (pix != kDeadPixel) {      // (a lane outside the rendered grid: bounce 0 only)
+        if (f.n_batch > 1) { it = pix >> kPixBits; pix &= (1u << kPixBits) - 1u; }
+        Rng<RNGM> rng;
+        rng.unpack((uint64_t)f2u(o4.w) | ((uint64_t)f2u(c4.w) << 32), ((uint64_t)(uint32_t)(f.iter0 + (float)it) << 1) | 1u);
+        using LT = LaneTrav<WIDE, SPILL>;
+        typename LT::Entry spill[LT::kSpill];
+        typename LT::Entry *stack = (typename LT::Entry *)s_stack + threadIdx.x;
+        const int lds_depth = (int)q.lds_depth;
+        V3 pass = mk3(0.0f, 0.0f, 0.0f);
+        for (uint32_t b = bounce0; b < f.max_bounces; b++) {
+            LT lt;
+            lt.begin(o, d);
+            Counts cnt = {0, 0};
+            bool more = sc.n_pairs != 0;
+            while (more) more = lt.at_leaf() ? lt.template leaf<false, EXT>(sc, s_order, stack, spill, lds_depth, cnt)
+                                             : lt.template inner<false>(sc, s_order, stack, spill, lds_depth, cnt);
+            if (b != 0) rays++;
+            const uint32_t id = lt.tr.best_id;
+            if (b == 0 && it + 1 == f.n_batch) hit_ids[pix] = id;
+            V3 emitted = mk3(0.0f, 0.0f, 0.0f);
+            bool alive = false;
+            if (id == kIdMiss) pass = shade_miss(f.p, d, color);
+            else alive = shade_hit<RNGM, EXT>(sc, o, d, lt.tr.best_t, id, rng, color, emitted, pass);
+            if (alive && b + 1 >= f.max_bounces) { alive = false; pass = mk3(0.0f, 0.0f, 0.0f); }      // "Kill ray after MAX_BOUNCES", compute.comp:457
+            if (!alive) break;
+        }
+        pass = pass * (1.0f / 1.0f);
+        pass_buf[(size_t)it * pass_stride + pix] = make_float4(pass.x, pass.y, pass.z, 0.0f);
+        }
+    }
+    rays = wave_sum(rays);
+    if ((threadIdx.x & 63u) == 0u && rays) atomicAdd(&stats->rays, rays);
+}
+
 // main()'s accumulation (compute.comp:470-476) for the iterations of a batch, in iteration order: every active pixel
 // owns exactly one path per iteration and k_wf_shade stored that path's radiance when it ended.
 __global__ __launch_bounds__(256) void k_wf_accumulate(Frame f, float4 *accum, const float4 *pass_buf, uint32_t pass_stride) {
@@ -615,7 +675,24 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     hipLaunchKernelGGL(k_wf_init, dim3(1), dim3(256), 0, stream, q, n_vt, n_active, stats);
     if (pcg) hipLaunchKernelGGL((k_wf_generate<1>), gen_grid, block, 0, stream, sc, f, q, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
     else hipLaunchKernelGGL((k_wf_generate<0>), gen_grid, block, 0, stream, sc, f, q, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
+    // small batches finish in k_wf_tail from this bounce on (0: never)
     for (uint32_t b = 0; b < f.max_bounces; b++) {
+        if (wf.tail_bounce >= 0 && b == (uint32_t)wf.tail_bounce) {      // small batches: the context decides (crt_context::TailTune)
+            q.lds_depth = fs.small_stack ? 1u : (sc.wide ? (uint32_t)kWideLds : (uint32_t)kLdsStack);
+            const bool wide = sc.wide != nullptr, spill = sc.ext != 0 || !(wide && sch.wide_levels <= q.lds_depth + 1u);
+            const dim3 tgrid((cap + 255) / 256);
+            const int variant = (pcg ? 8 : 0) | (wide ? 4 : 0) | (spill ? 2 : 0) | (sc.ext ? 1 : 0);
+            switch (variant) {
+#define CRT_TAIL_CASE(V, R, W, S, A) case V: hipLaunchKernelGGL((k_wf_tail<R, W, S, A>), tgrid, block, 0, stream, sc, f, q, b, b == 0 ? dead : 0ull, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats); break;
+                CRT_TAIL_CASE(2, 0, false, true, false)  CRT_TAIL_CASE(3, 0, false, true, true)
+                CRT_TAIL_CASE(4, 0, true, false, false)  CRT_TAIL_CASE(6, 0, true, true, false)  CRT_TAIL_CASE(7, 0, true, true, true)
+                CRT_TAIL_CASE(10, 1, false, true, false)  CRT_TAIL_CASE(11, 1, false, true, true)
+                CRT_TAIL_CASE(12, 1, true, false, false)  CRT_TAIL_CASE(14, 1, true, true, false)  CRT_TAIL_CASE(15, 1, true, true, true)
+#undef CRT_TAIL_CASE
+                default: break;
+            }
+            break;
+        }
         const unsigned long long dead_b = b == 0 ? dead : 0ull;
         if (wf.time_kernels) {      // three events per bounce: before extend, between extend and shade, after shade
             while (wf.ev_used + 3 > wf.ev.size()) { hipEvent_t a; HIP_TRY(hipEventCreate(&a)); wf.ev.push_back(a); }

@@ -190,7 +190,8 @@ int crt_set_instrumented(crt_context *ctx, int on);
 int crt_loop_counters_read(crt_context *ctx, uint64_t *out, uint32_t n_words);
 /* Brackets every k_wf_extend launch (the dominant kernel) and every k_wf_shade launch with HIP events on the context's
  * stream so that crt_stats.last_extend_ms / last_shade_ms report their device time separately (bench.py's roofline
- * figures).  While it is on, crt_dispatch / crt_render wait for the previous call's events before reusing them. */
+ * figures).  While it is on, crt_dispatch / crt_render wait for the previous call's events before reusing them, and
+ * small batches stay on the per-bounce kernels (CRT_FLAG_PER_BOUNCE_KERNELS, types.h). */
 int crt_set_kernel_timing(crt_context *ctx, int on);
 
 /* Read back the build's BVH for cross-checks: nodes (pair layout, see

@@ -163,9 +163,15 @@ enum {
 enum {
     CRT_FLAG_FULL_IMAGE = 1u << 0, /* render all W x H pixels; default renders floor(W/8)*8 x floor(H/8)*8
                                       like dispatch(W/8, H/8, 1), vk_engine.cpp:1435 */
-    CRT_FLAG_DEBUG_SMALL_STACK = 1u << 1 /* test hook: the wavefront tracer keeps one traversal-stack entry per lane in LDS,
+    CRT_FLAG_DEBUG_SMALL_STACK = 1u << 1, /* test hook: the wavefront tracer keeps one traversal-stack entry per lane in LDS,
                                       so the scratch-memory overflow path (otherwise only reached by trees deeper than the
                                       LDS stack) runs on every scene */
+    /* Small wavefront batches (up to 4.2 M paths: one sample of a 1080p frame) can run as a k_wf_extend / k_wf_shade pair
+     * per bounce or, each path through all its bounces in one lane, in k_wf_tail.  The image is the same bit for bit;
+     * which is faster depends on the scene, so by default the context times both over its first dispatches and keeps
+     * the faster (context.hip, TailTune).  These two flags fix the choice. */
+    CRT_FLAG_PER_BOUNCE_KERNELS = 1u << 2,
+    CRT_FLAG_PATH_KERNEL = 1u << 3
 };
 
 /* crt_extensions_set: build extensions with no counterpart in the reference, all off by default.

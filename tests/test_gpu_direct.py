@@ -164,3 +164,74 @@ def test_direct_mode_errors(ctx):
     ctx.render(scene.params_for(1, seeds[0]), 1, seeds)
     ctx.sync()
     assert len(ctx.bvh()[0]) > 0
+
+
+# ---- small batches: a kernel pair per bounce or one lane per path (k_wf_tail); CRT_FLAG_PER_BOUNCE_KERNELS / CRT_FLAG_PATH_KERNEL ----
+MODES = [abi.FLAG_PER_BOUNCE_KERNELS, abi.FLAG_PATH_KERNEL]
+
+
+@pytest.mark.parametrize("name,w,h,n_iter,bvh,rng", [("book1", 200, 112, 3, abi.BVH_SAH_REFINE | abi.BVH_WIDE, abi.RNG_REF),
+                                                    ("book1", 128, 72, 3, abi.BVH_LBVH, abi.RNG_PCG),
+                                                    ("corne", 100, 50, 2, abi.BVH_SAH_REFINE, abi.RNG_REF),       # ragged: lanes outside the rendered grid
+                                                    ("cirno", 96, 60, 2, DIRECT, abi.RNG_REF),
+                                                    ("voxel_city", 640, 360, 2, abi.BVH_SAH_REFINE | abi.BVH_WIDE, abi.RNG_PCG)],
+                         ids=["book1-wide", "book1-pairs-pcg", "corne-ragged", "cirno-direct", "voxel-640-pcg"])
+def test_path_kernel_and_per_bounce_kernels_match_the_oracle(golden_dir, name, w, h, n_iter, bvh, rng):
+    scene = abi.builtin_scene(name, w, h, golden_dir)
+    ref, rays = None, []
+    for mode in MODES:
+        c = abi.Context(0)
+        try:
+            img, ids, ps = _gpu_render(c, scene, w, h, n_iter, bvh=bvh, tracer=abi.TRACER_WAVEFRONT, rng_mode=rng, flags=mode)
+            if ref is None:
+                ref = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_FAST | (orc.RNG_PCG if rng == abi.RNG_PCG else 0))
+            assert np.array_equal(ids, ref[1]), f"mode {mode}: {(ids != ref[1]).sum()} primary-hit ID mismatches"
+            assert np.array_equal(img.view(np.uint32), ref[0].view(np.uint32)), f"mode {mode}"
+            rays.append(c.stats().rays)
+        finally:
+            c.close()
+    assert rays[0] == rays[1] == ref[2].rays          # both count hit_world calls
+
+
+def test_path_kernel_debug_view_and_extensions(golden_dir):
+    """R15's outline view (samples killed before any traversal) and the build extensions through k_wf_tail."""
+    from test_gpu_extensions import _cutout_scene
+    w, h = 96, 64
+    scene = _cutout_scene(w, h)
+    ext, orc_ext = abi.EXT_TEXTURE_INDEX | abi.EXT_ALPHA_TEST, orc.EXT_TEXTURE_INDEX | orc.EXT_ALPHA_TEST
+    ps = [scene.params_for(i + 1, s) for i, s in enumerate(abi.frame_seeds(0, 2))]
+    ref = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_BRUTE | orc_ext)
+    for mode in MODES:
+        c = abi.Context(0)
+        try:
+            c.configure(w, h, tracer=abi.TRACER_WAVEFRONT, flags=mode)
+            c.extensions_set(ext)
+            c.upload(scene)
+            c.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE)
+            c.render(ps[0], 1, abi.frame_seeds(0, 2))
+            c.sync()
+            assert np.array_equal(c.hit_ids(), ref[1]) and np.array_equal(c.image().view(np.uint32), ref[0].view(np.uint32)), f"mode {mode}"
+        finally:
+            c.close()
+
+
+def test_mode_is_measured_and_then_kept(golden_dir):
+    """Default (no flag): the first dispatches alternate between the two forms, then one is kept; every frame is the
+    oracle's whichever form rendered it."""
+    w, h = 128, 72
+    scene = abi.builtin_scene("book1", w, h)
+    c = abi.Context(0)
+    try:
+        c.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+        c.upload(scene)
+        c.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE)
+        seeds = abi.frame_seeds(0, 16)
+        ps = [scene.params_for(i + 1, seeds[i]) for i in range(16)]
+        for i in range(16):
+            c.dispatch(ps[i])
+        c.sync()
+        ref_img, ref_ids, cnt = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_FAST)
+        assert np.array_equal(c.hit_ids(), ref_ids) and np.array_equal(c.image().view(np.uint32), ref_img.view(np.uint32))
+        assert c.stats().rays == cnt.rays
+    finally:
+        c.close()
