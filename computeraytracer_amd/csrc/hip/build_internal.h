@@ -30,7 +30,7 @@ struct BuildState {
     uint32_t sah_tiers = 0;
     // results (what traversal reads)
     DeviceBuffer pairs, tri_pack, sphere_pack, quad_pack, sphere_ids, quad_ids, tri_ids;
-    DeviceBuffer tri_shade;        // 64-byte shading record per triangle, input order (bvh_build.hip: write_tri_shade)
+    DeviceBuffer tri_shade;        // 64-byte shading record per triangle, input order (bvh_build.hip: k_tri_bounds)
     // 8-wide quantised nodes (bvh_wide.hip, CRT_BVH_WIDE): n_wide nodes of kWideStrideF4 float4 each, BFS order
     DeviceBuffer wide, wide_queue[2], wide_levels_dev;
     uint32_t wide_cap = 0;     // nodes the `wide` allocation was laid out for: the links start kWideStrideF4 * wide_cap float4 in

@@ -40,35 +40,10 @@ __global__ void k_init_bounds(uint32_t *b) {
 // u0, u1} {u2, v0, v1, v2}.  The 96-byte upload record put materialIndex 92 bytes after v0 (a second line for every
 // other triangle) and the shader's two edge subtractions in front of every hit; e10 / e20 are those same IEEE
 // subtractions (compute.comp:281-282), done once here.
-__device__ __forceinline__ void write_tri_shade(const BuildInput &in, uint32_t g, float4 *tri_shade) {
-    const uint32_t i = g - in.n_spheres - in.n_quads;
-    const float4 *p = (const float4 *)(in.tris + i);
-    const float4 v0 = p[0], v1 = p[1], v2 = p[2], tu = p[3], tv = p[4], last = p[5];
-    float4 *o = tri_shade + 4 * (size_t)i;
-    o[0] = make_float4(v0.x, v0.y, v0.z, v1.x - v0.x);
-    o[1] = make_float4(v1.y - v0.y, v1.z - v0.z, v2.x - v0.x, v2.y - v0.y);
-    o[2] = make_float4(v2.z - v0.z, last.w, tu.x, tu.y);
-    o[3] = make_float4(tu.z, tv.x, tv.y, tv.z);
-}
 
-// BOXES = false (CRT_BVH_WIDE_DIRECT, which takes the boxes from the shading records later): only the centroid is kept,
-// in plo: 16 instead of 32 bytes written here and read by k_morton.
-template <bool BOXES>
-__global__ __launch_bounds__(256) void k_prim_bounds(BuildInput in, uint32_t n, float4 *plo, float4 *phi, float4 *tri_shade, uint32_t *scene_bounds) {
-    // grid-stride: the grid is capped (build_bvh) so that the atomics below stay a few thousand however large n is
-    uint32_t cmn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, cmx[3] = {0u, 0u, 0u};
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
-        float lo[3], hi[3];
-        prim_box(in, g, lo, hi);
-        if (g >= in.n_spheres + in.n_quads) write_tri_shade(in, g, tri_shade);
-        if (BOXES) {
-            plo[g] = make_float4(lo[0], lo[1], lo[2], 0.0f);
-            phi[g] = make_float4(hi[0], hi[1], hi[2], 0.0f);
-        } else plo[g] = make_float4(0.5f * lo[0] + 0.5f * hi[0], 0.5f * lo[1] + 0.5f * hi[1], 0.5f * lo[2] + 0.5f * hi[2], 0.0f);
-        for (int a = 0; a < 3; a++) { const uint32_t e = enc_f(0.5f * lo[a] + 0.5f * hi[a]); cmn[a] = min(cmn[a], e); cmx[a] = max(cmx[a], e); }
-    }
-    // block-level min/max of the centroids (wave shuffles, then LDS), one atomic per block and axis: the six result
-    // words are a single hot line, so the number of atomics, not their width, sets this kernel's time
+// Block-level min/max of the centroids (wave shuffles, then LDS), one atomic per block and axis: the six result words
+// are a single hot line, so the number of atomics, not their width, sets the time of the kernels below.
+__device__ __forceinline__ void reduce_centroid_bounds(uint32_t cmn[3], uint32_t cmx[3], uint32_t *scene_bounds) {
     __shared__ uint32_t s_red[6][4];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int a = 0; a < 3; a++) {
@@ -86,6 +61,75 @@ __global__ __launch_bounds__(256) void k_prim_bounds(BuildInput in, uint32_t n, 
         for (uint32_t w = 1; w < nw; w++) v = threadIdx.x < 3 ? min(v, s_red[threadIdx.x][w]) : max(v, s_red[threadIdx.x][w]);
         if (threadIdx.x < 3) atomicMin(&scene_bounds[threadIdx.x], v); else atomicMax(&scene_bounds[threadIdx.x], v);
     }
+}
+
+// Spheres and quads (primitives [0, n) of the build's numbering; the triangles follow and go through k_tri_bounds).
+// BOXES = false (CRT_BVH_WIDE_DIRECT, which takes the boxes from the packed records later): only the centroid is kept,
+// in plo: 16 instead of 32 bytes written here and read by k_morton.
+template <bool BOXES>
+__global__ __launch_bounds__(256) void k_prim_bounds(BuildInput in, uint32_t n, float4 *plo, float4 *phi, uint32_t *scene_bounds) {
+    // grid-stride: the grid is capped (build_bvh) so that the atomics stay a few thousand however large n is
+    uint32_t cmn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, cmx[3] = {0u, 0u, 0u};
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
+        float lo[3], hi[3];
+        prim_box(in, g, lo, hi);
+        if (BOXES) {
+            plo[g] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+            phi[g] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+        } else plo[g] = make_float4(0.5f * lo[0] + 0.5f * hi[0], 0.5f * lo[1] + 0.5f * hi[1], 0.5f * lo[2] + 0.5f * hi[2], 0.0f);
+        for (int a = 0; a < 3; a++) { const uint32_t e = enc_f(0.5f * lo[a] + 0.5f * hi[a]); cmn[a] = min(cmn[a], e); cmx[a] = max(cmx[a], e); }
+    }
+    reduce_centroid_bounds(cmn, cmx, scene_bounds);
+}
+
+// Triangles: box (or centroid), centroid bounds and the 64-byte shading record (layout above).  A wave
+// moves its 64 records through LDS, 6 KiB in and 4 KiB out, so that global loads and stores are 16 bytes per lane over
+// consecutive addresses and every line crosses the L1 once; one record per lane straight from global memory is six
+// accesses at a 96-byte stride whose lines do not survive in the L1 between the first and the sixth (k_animate_tris has
+// the numbers).  first = index of triangle 0 in the build's numbering (spheres + quads).
+template <bool BOXES>
+__global__ __launch_bounds__(256) void k_tri_bounds(const crt_tri *tris, uint32_t n_tris, uint32_t first, float4 *plo, float4 *phi, float4 *tri_shade, uint32_t *scene_bounds) {
+    __shared__ float4 s_rec[4][64 * 6];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 *sw = s_rec[wave];
+    uint32_t cmn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, cmx[3] = {0u, 0u, 0u};
+    const uint32_t n_chunks = (n_tris + 63u) / 64u, per_round = gridDim.x * 4u;
+    for (uint32_t round = 0; round * per_round < n_chunks; round++) {      // same trip count for every wave of the block (barriers inside)
+        const uint32_t chunk = round * per_round + blockIdx.x * 4u + wave;
+        const uint32_t base = chunk * 64u;
+        const uint32_t cnt = chunk < n_chunks ? min(64u, n_tris - base) : 0u;
+        const float4 *src = (const float4 *)(tris + base);
+#pragma unroll
+        for (uint32_t k = 0; k < 6; k++) { const uint32_t idx = k * 64 + lane; if (idx < cnt * 6) sw[idx] = src[idx]; }
+        __syncthreads();
+        float4 o0, o1, o2, o3;
+        if (lane < cnt) {
+            const float4 v0 = sw[lane * 6], v1 = sw[lane * 6 + 1], v2 = sw[lane * 6 + 2], tu = sw[lane * 6 + 3], tv = sw[lane * 6 + 4], last = sw[lane * 6 + 5];
+            float lo[3], hi[3];
+            lo[0] = fminf(fminf(v0.x, v1.x), v2.x); hi[0] = fmaxf(fmaxf(v0.x, v1.x), v2.x);
+            lo[1] = fminf(fminf(v0.y, v1.y), v2.y); hi[1] = fmaxf(fmaxf(v0.y, v1.y), v2.y);
+            lo[2] = fminf(fminf(v0.z, v1.z), v2.z); hi[2] = fmaxf(fmaxf(v0.z, v1.z), v2.z);
+            pad_box(lo, hi);
+            const uint32_t g = first + base + lane;
+            if (BOXES) {
+                plo[g] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+                phi[g] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+            } else plo[g] = make_float4(0.5f * lo[0] + 0.5f * hi[0], 0.5f * lo[1] + 0.5f * hi[1], 0.5f * lo[2] + 0.5f * hi[2], 0.0f);
+            for (int a = 0; a < 3; a++) { const uint32_t e = enc_f(0.5f * lo[a] + 0.5f * hi[a]); cmn[a] = min(cmn[a], e); cmx[a] = max(cmx[a], e); }
+            o0 = make_float4(v0.x, v0.y, v0.z, v1.x - v0.x);
+            o1 = make_float4(v1.y - v0.y, v1.z - v0.z, v2.x - v0.x, v2.y - v0.y);
+            o2 = make_float4(v2.z - v0.z, last.w, tu.x, tu.y);
+            o3 = make_float4(tu.z, tv.x, tv.y, tv.z);
+        }
+        __syncthreads();
+        if (lane < cnt) { sw[lane * 4] = o0; sw[lane * 4 + 1] = o1; sw[lane * 4 + 2] = o2; sw[lane * 4 + 3] = o3; }
+        __syncthreads();
+        float4 *dst = tri_shade + 4 * (size_t)base;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) { const uint32_t idx = k * 64 + lane; if (idx < cnt * 4) dst[idx] = sw[idx]; }
+        __syncthreads();
+    }
+    reduce_centroid_bounds(cmn, cmx, scene_bounds);
 }
 
 // Spread the low 21 bits of v to every third bit.
@@ -429,14 +473,32 @@ __global__ void k_single_pair(const uint32_t *vals, const float4 *plo, const flo
 // Config 5 animation: y = rest_y + amplitude * sin(frame + x + z) on every triangle vertex.
 // sinf is OCML's accurate single-precision sine (full argument reduction), not the __sinf hardware approximation: the
 // result feeds the BVH build and the tracer, and tests/test_gpu_parity.py checks it against float64 sin to 2 ulp.
-__global__ void k_animate_tris(uint32_t n, const crt_tri *rest, crt_tri *out, float frame, float amplitude) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    crt_tri t = rest[i];
-    t.v0[1] = t.v0[1] + amplitude * sinf((frame + t.v0[0]) + t.v0[2]);
-    t.v1[1] = t.v1[1] + amplitude * sinf((frame + t.v1[0]) + t.v1[2]);
-    t.v2[1] = t.v2[1] + amplitude * sinf((frame + t.v2[0]) + t.v2[2]);
-    out[i] = t;
+// A wave moves its 64 triangles (6 KiB, contiguous) through LDS: global loads and stores are 16 bytes per lane over
+// consecutive addresses, every line crosses the L1 once.  (One 96-byte record per lane straight from global memory is six
+// 16-byte accesses at a 96-byte stride; with eight waves a CU their 48 KiB of lines do not survive in the 32 KiB L1
+// between the first and the sixth access: 520 us for 10 M triangles.)
+__global__ __launch_bounds__(256) void k_animate_tris(uint32_t n, const crt_tri *rest, crt_tri *out, float frame, float amplitude) {
+    __shared__ float4 s_rec[4][64 * 6];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t base = ((uint64_t)blockIdx.x * 4 + wave) * 64;      // first triangle of this wave
+    const uint32_t cnt = base < n ? (uint32_t)min((uint64_t)64, n - base) : 0u;
+    const float4 *src = (const float4 *)(rest + base);
+    float4 *dst = (float4 *)(out + base);
+    float4 *sw = s_rec[wave];
+#pragma unroll
+    for (uint32_t k = 0; k < 6; k++) { const uint32_t idx = k * 64 + lane; if (idx < cnt * 6) sw[idx] = src[idx]; }
+    __syncthreads();
+    if (lane < cnt) {
+#pragma unroll
+        for (uint32_t v = 0; v < 3; v++) {      // rows 0..2 of the record: v0, v1, v2
+            float4 p = sw[lane * 6 + v];
+            p.y = p.y + amplitude * sinf((frame + p.x) + p.z);
+            sw[lane * 6 + v] = p;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < 6; k++) { const uint32_t idx = k * 64 + lane; if (idx < cnt * 6) dst[idx] = sw[idx]; }
 }
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return false; } } while (0)
@@ -526,10 +588,21 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     if (!ensure(st.temp, std::max(sort_bytes, scan_bytes), err)) return false;
 
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, (uint32_t *)st.scene_bounds.ptr);
-    if (direct) hipLaunchKernelGGL(k_prim_bounds<false>, dim3(std::min(blocks, 4096u)), dim3(256), 0, stream, in, n, (float4 *)st.plo.ptr, (float4 *)nullptr,
-                                   (float4 *)st.tri_shade.ptr, (uint32_t *)st.scene_bounds.ptr);
-    else hipLaunchKernelGGL(k_prim_bounds<true>, dim3(std::min(blocks, 4096u)), dim3(256), 0, stream, in, n, (float4 *)st.plo.ptr, (float4 *)st.phi.ptr,
-                            (float4 *)st.tri_shade.ptr, (uint32_t *)st.scene_bounds.ptr);
+    {
+        const uint32_t n_other = in.n_spheres + in.n_quads;
+        float4 *plo = (float4 *)st.plo.ptr, *phi = direct ? nullptr : (float4 *)st.phi.ptr;
+        uint32_t *sb = (uint32_t *)st.scene_bounds.ptr;
+        if (n_other) {
+            const dim3 g(std::min((n_other + 255u) / 256u, 4096u));
+            if (direct) hipLaunchKernelGGL(k_prim_bounds<false>, g, dim3(256), 0, stream, in, n_other, plo, phi, sb);
+            else hipLaunchKernelGGL(k_prim_bounds<true>, g, dim3(256), 0, stream, in, n_other, plo, phi, sb);
+        }
+        if (in.n_tris) {
+            const dim3 g(std::min((in.n_tris + 255u) / 256u, 4096u));
+            if (direct) hipLaunchKernelGGL(k_tri_bounds<false>, g, dim3(256), 0, stream, in.tris, in.n_tris, n_other, plo, phi, (float4 *)st.tri_shade.ptr, sb);
+            else hipLaunchKernelGGL(k_tri_bounds<true>, g, dim3(256), 0, stream, in.tris, in.n_tris, n_other, plo, phi, (float4 *)st.tri_shade.ptr, sb);
+        }
+    }
     hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, bits, idx_bits, (const float4 *)st.plo.ptr,
                        direct ? (const float4 *)nullptr : (const float4 *)st.phi.ptr, (const uint32_t *)st.scene_bounds.ptr, (uint64_t *)st.keys.ptr, (uint32_t *)st.vals.ptr);
     HIP_TRY(hipGetLastError());

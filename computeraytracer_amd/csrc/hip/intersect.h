@@ -344,7 +344,7 @@ CRT_DEV void resolve_hit(const DeviceScene &sc, V3 o, V3 d, float t, uint32_t id
     if (kind == CRT_ID_KIND_TRI) {                       // compute.comp:303-307
         const float4 *p = sc.tri_shade + 4 * (size_t)idx;
         const float4 a = PRE ? pre.a : p[0], b = PRE ? pre.b : p[1], c = PRE ? pre.c : p[2];
-        const V3 e10 = mk3(a.w, b.x, b.y), e20 = mk3(b.z, b.w, c.x);      // v1 - v0, v2 - v0 (bvh_build.hip: write_tri_shade)
+        const V3 e10 = mk3(a.w, b.x, b.y), e20 = mk3(b.z, b.w, c.x);      // v1 - v0, v2 - v0 (bvh_build.hip: k_tri_bounds)
         set_face_normal(d, cross3(e20, e10), rec);       // not normalised (sic)
         rec.materialIndex = f2u(c.y);
     } else if (kind == CRT_ID_KIND_SPHERE) {             // compute.comp:241-245
