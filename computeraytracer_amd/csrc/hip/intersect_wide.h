@@ -86,30 +86,25 @@ CRT_DEV f32x2 ubyte_f2(uint32_t w, int k) { f32x2 r; r.x = ubyte_f(w, k); r.y = 
 CRT_DEV f32x2 splat2(float v) { f32x2 r; r.x = v; r.y = v; return r; }
 CRT_DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }        // v_pk_fma_f32
 
-// Node visit without the final wide_advance: tests the eight children of node tr.cur and makes them the top group.
-template <bool COUNT, bool SPILL>
-CRT_DEV void wide_visit(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_t stack_stride, uint2 *spill, int lds_depth, Counts &cnt) {
-    const uint32_t node = tr.cur;
-    const float4 *p = nodes + (size_t)kWideNodeF4 * node;
-    const float4 h = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
-    if (COUNT) cnt.nodes += 8;
+// The eight slab tests of one node (its four 16-byte rows) for one ray: hit mask, bit = slot.
+CRT_DEV uint32_t wide_test8(float4 h, float4 r1, float4 r2, float4 r3, V3 idir, V3 noid, float tfar) {
     const uint32_t hx = f2u(h.x), hy = f2u(h.y), hz = f2u(h.z);
     constexpr float kErr = 4.76837158203125e-07f;      // 2^-21
     // per-axis plane coefficients: t_near = q * a + bn, t_far = q * a + bf.  Bit 8 of a header word is zero, so
     // word << 23 is the grid step 2^(e - 127) as a float.
-    const float ax = tr.idir.x * u2f(hx << 23), ay = tr.idir.y * u2f(hy << 23), az = tr.idir.z * u2f(hz << 23);
-    const float bx = __builtin_fmaf(u2f(hx & 0xFFFFFE00u), tr.idir.x, tr.noid.x);
-    const float by = __builtin_fmaf(u2f(hy & 0xFFFFFE00u), tr.idir.y, tr.noid.y);
-    const float bz = __builtin_fmaf(u2f(hz & 0xFFFFFE00u), tr.idir.z, tr.noid.z);
+    const float ax = idir.x * u2f(hx << 23), ay = idir.y * u2f(hy << 23), az = idir.z * u2f(hz << 23);
+    const float bx = __builtin_fmaf(u2f(hx & 0xFFFFFE00u), idir.x, noid.x);
+    const float by = __builtin_fmaf(u2f(hy & 0xFFFFFE00u), idir.y, noid.y);
+    const float bz = __builtin_fmaf(u2f(hz & 0xFFFFFE00u), idir.z, noid.z);
     // |t| <= |b| + 255 |a| for every plane of this node, so err below covers the relative part of the error too
-    const float ex = __builtin_fmaf(__builtin_fabsf(ax), 256.0f, __builtin_fabsf(tr.noid.x) + __builtin_fabsf(bx)) * kErr;
-    const float ey = __builtin_fmaf(__builtin_fabsf(ay), 256.0f, __builtin_fabsf(tr.noid.y) + __builtin_fabsf(by)) * kErr;
-    const float ez = __builtin_fmaf(__builtin_fabsf(az), 256.0f, __builtin_fabsf(tr.noid.z) + __builtin_fabsf(bz)) * kErr;
+    const float ex = __builtin_fmaf(__builtin_fabsf(ax), 256.0f, __builtin_fabsf(noid.x) + __builtin_fabsf(bx)) * kErr;
+    const float ey = __builtin_fmaf(__builtin_fabsf(ay), 256.0f, __builtin_fabsf(noid.y) + __builtin_fabsf(by)) * kErr;
+    const float ez = __builtin_fmaf(__builtin_fabsf(az), 256.0f, __builtin_fabsf(noid.z) + __builtin_fabsf(bz)) * kErr;
     const f32x2 ax2 = splat2(ax), ay2 = splat2(ay), az2 = splat2(az);
     const f32x2 bnx = splat2(bx - ex), bny = splat2(by - ey), bnz = splat2(bz - ez);
     const f32x2 bfx = splat2(bx + ex), bfy = splat2(by + ey), bfz = splat2(bz + ez);
     // near planes are the low ones for a non-negative direction component, the high ones otherwise
-    const bool nx = (int32_t)f2u(tr.idir.x) < 0, ny = (int32_t)f2u(tr.idir.y) < 0, nz = (int32_t)f2u(tr.idir.z) < 0;
+    const bool nx = (int32_t)f2u(idir.x) < 0, ny = (int32_t)f2u(idir.y) < 0, nz = (int32_t)f2u(idir.z) < 0;
     const uint32_t lox[2] = {f2u(r1.x), f2u(r1.y)}, loy[2] = {f2u(r1.z), f2u(r1.w)}, loz[2] = {f2u(r2.x), f2u(r2.y)};
     const uint32_t hix[2] = {f2u(r2.z), f2u(r2.w)}, hiy[2] = {f2u(r3.x), f2u(r3.y)}, hiz[2] = {f2u(r3.z), f2u(r3.w)};
     uint32_t m = 0;
@@ -124,13 +119,24 @@ CRT_DEV void wide_visit(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_
             const f32x2 tny = fma2(ubyte_f2(qny, k), ay2, bny), tfy = fma2(ubyte_f2(qfy, k), ay2, bfy);
             const f32x2 tnz = fma2(ubyte_f2(qnz, k), az2, bnz), tfz = fma2(ubyte_f2(qfz, k), az2, bfz);
             const float tn0 = __builtin_fmaxf(__builtin_fmaxf(tnx.x, tny.x), __builtin_fmaxf(tnz.x, 0.0f));
-            const float tf0 = __builtin_fminf(__builtin_fminf(tfx.x, tfy.x), __builtin_fminf(tfz.x, tr.tfar));
+            const float tf0 = __builtin_fminf(__builtin_fminf(tfx.x, tfy.x), __builtin_fminf(tfz.x, tfar));
             const float tn1 = __builtin_fmaxf(__builtin_fmaxf(tnx.y, tny.y), __builtin_fmaxf(tnz.y, 0.0f));
-            const float tf1 = __builtin_fminf(__builtin_fminf(tfx.y, tfy.y), __builtin_fminf(tfz.y, tr.tfar));
+            const float tf1 = __builtin_fminf(__builtin_fminf(tfx.y, tfy.y), __builtin_fminf(tfz.y, tfar));
             if (tn0 <= tf0) m |= 1u << (4 * w + k);
             if (tn1 <= tf1) m |= 1u << (4 * w + k + 1);
         }
     }
+    return m;
+}
+
+// Node visit without the final wide_advance: tests the eight children of node tr.cur and makes them the top group.
+template <bool COUNT, bool SPILL>
+CRT_DEV void wide_visit(const float4 *nodes, WideTrav &tr, uint2 *stack, uint32_t stack_stride, uint2 *spill, int lds_depth, Counts &cnt) {
+    const uint32_t node = tr.cur;
+    const float4 *p = nodes + (size_t)kWideNodeF4 * node;
+    const float4 h = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+    if (COUNT) cnt.nodes += 8;
+    const uint32_t m = wide_test8(h, r1, r2, r3, tr.idir, tr.noid, tr.tfar);
     if (m != 0u) {
         if ((tr.g_pend & 0xFFu) != 0u) {
             const uint2 e = make_uint2(tr.g_hdr, tr.g_pend);

@@ -424,6 +424,102 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
     }
 }
 
+// Bounce 0 of the 8-wide tree as PACKETS: the 64 primary rays of a queue batch are the 8 x 8 pixels of one tile, so they
+// walk nearly the same nodes.  The wave keeps ONE cursor and ONE stack for all of them (wave-uniform values: scalar
+// registers, scalar branches, one memory request per node instead of up to 64); a node is entered when ANY lane's ray
+// enters its box, every lane tests the eight children against its own ray and its own best hit, and the leaf tests run
+// for all lanes at once.  A lane thus also tests boxes and primitives that its own traversal would have skipped: tests
+// that can only fail (a ray that hits a primitive enters every box around it), so hits and IDs are those of k_wf_extend.
+// Children are visited in the order of the packet's first ray's octant.
+__global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_primary(DeviceScene sc, WfQueues q, unsigned long long dead, DeviceStats *stats) {
+    __shared__ uint2 s_stack[4][kWideSpill + 2];
+    __shared__ uint8_t s_order[kWideOrderBytes];
+    wide_order_table(s_order, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t *counts = q.counts;
+    uint32_t *cursors = q.cursors;
+    const float4 *ro = q.ray_o[0], *rd = q.ray_d[0];
+    if (blockIdx.x == 0) {
+        unsigned long long n = wave_sum(threadIdx.x < kShards ? (unsigned long long)counts[threadIdx.x * kCtrStride] : 0ull);
+        if (lane == 0) atomicAdd(&stats->rays, n - (wave == 0 ? dead : 0ull));
+    }
+    const uint32_t ns = q.n_shards, per = ns >= 8 ? ns / 8 : 1;
+    const uint32_t home = home_shard(blockIdx.x, wave, ns);
+    const uint32_t waves_here = max(1u, (gridDim.x * 4u) / ns);
+    uint2 *stack = s_stack[wave];
+    uint32_t k = 0, pool_next = 0, pool_end = 0, pool_base = 0;
+    for (;;) {
+        if (pool_next >= pool_end) {
+            while (k < ns) {
+                const uint32_t s = ns >= 8 ? (home + 8 * (k % per) + (k / per)) % ns : (home + k) % ns;
+                const uint32_t n = counts[s * kCtrStride];
+                uint32_t base = n;
+                if (n != 0) {
+                    const uint32_t fetch = min(kFetchBatches, max(1u, n / (waves_here * 64u * 8u)));
+                    uint32_t *cursor = cursors + s * kCtrStride;
+                    if (lane == 0 && *(volatile uint32_t *)cursor < n) base = atomicAdd(cursor, 64u * fetch);
+                    base = __shfl(base, 0);
+                    if (base < n) { pool_base = s * q.shard_cap; pool_next = base; pool_end = min(n, base + 64u * fetch); break; }
+                }
+                k++;
+                {
+                    const uint32_t kk = k + lane;
+                    const uint32_t sl = ns >= 8 ? (home + 8 * (kk % per) + (kk / per)) % ns : (home + kk) % ns;
+                    const bool live = kk < ns && *(volatile uint32_t *)(cursors + sl * kCtrStride) < counts[sl * kCtrStride];
+                    const unsigned long long m = __ballot(live);
+                    k = m ? k + (uint32_t)__builtin_ctzll(m) : ns;
+                }
+            }
+            if (k >= ns) break;
+        }
+        const uint32_t i = pool_next + lane;
+        pool_next = min(pool_end, pool_next + 64u);
+        const bool in_pool = i < pool_end;
+        const uint32_t slot = pool_base + (in_pool ? i : pool_end - 1u);
+        const float4 o4 = ro[slot], d4 = rd[slot];
+        const bool active = in_pool && f2u(d4.w) != kDeadPixel;
+        const unsigned long long act = __ballot(active);
+        WideTrav tr;
+        wide_begin(tr, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z));
+        if (act != 0ull && sc.n_pairs != 0) {
+            const uint32_t oct8 = (uint32_t)__builtin_amdgcn_readlane((int)tr.oct8, (int)__builtin_ctzll(act));
+            uint32_t cur = 0, g_hdr = 0, g_pend = 0, sp = 0;      // wave-uniform
+            for (;;) {
+                if (!(cur & kLeafTag)) {
+                    const float4 *p = sc.wide + (size_t)kWideNodeF4 * cur;
+                    const float4 h = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+                    const uint32_t m = active ? wide_test8(h, r1, r2, r3, tr.idir, tr.noid, tr.best_t * 1.000004f) : 0u;
+                    uint32_t any = 0;
+#pragma unroll
+                    for (uint32_t sl = 0; sl < 8; sl++) if (__ballot((m >> sl) & 1u) != 0ull) any |= 1u << sl;
+                    if (any != 0u) {
+                        if ((g_pend & 0xFFu) != 0u) { if (lane == 0) stack[sp] = make_uint2(g_hdr, g_pend); sp++; }
+                        g_hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(h.w));
+                        g_pend = (cur << 8) | any;
+                    }
+                } else {
+                    const uint32_t e = cur, kind = (e >> 29) & 3u, n = ((e >> 26) & 7u) + 1u, first = e & (kMaxLeafLink - 1u);
+                    Counts cnt = {0, 0};
+                    if (kind != 3u && active) test_leaf<false, false>(sc, tr.o, tr.d, first, (kind << 28) | n, tr.best_t, tr.best_id, cnt);
+                }
+                if ((g_pend & 0xFFu) == 0u) {
+                    if (sp == 0u) break;
+                    sp--;
+                    const uint2 e = stack[sp];
+                    g_hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x); g_pend = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+                }
+                const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_order[oct8 | (g_pend & 0xFFu)]);
+                const uint32_t bit = 1u << sl, imask = g_hdr & 0xFFu;
+                g_pend ^= bit;
+                if (imask & bit) cur = (g_hdr >> 8) + (uint32_t)__builtin_popcount(imask & (bit - 1u));
+                else cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.wide_links[(size_t)(g_pend >> 8) * 8u + sl]);
+            }
+        }
+        if (in_pool) q.hit[slot] = make_uint2(f2u(tr.best_t), tr.best_id);
+    }
+}
+
 #ifndef CRT_SHADE_WAVES
 #define CRT_SHADE_WAVES 6
 #endif
@@ -700,8 +796,14 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
         }
         q.lds_depth = fs.small_stack ? 1u : (sc.wide ? (uint32_t)kWideLds : (uint32_t)kLdsStack);
         // wide trees of at most lds_depth + 1 levels never overflow the LDS stack (at most levels - 1 groups wait on it)
-        launch_extend<0>(fs.instrumented, sc.wide != nullptr, !(sc.wide && sch.wide_levels <= q.lds_depth + 1u), sc.ext != 0,
-                         pgrid, stream, sc, q, b, dead_b, stats);
+        // bounce 0 over the 8-wide tree: tiles of primary rays as packets (k_wf_primary; 7 and 8 waves per SIMD measured slower
+        // than 6).  The instrumented and the extension kernels stay per ray.
+        static const bool env_primary = [] { const char *e = getenv("CRT_WF_PRIMARY"); return !e || atoi(e) != 0; }();
+        if (b == 0 && env_primary && sc.wide && !sc.ext && !fs.instrumented && sch.wide_levels <= kWideSpill)
+            hipLaunchKernelGGL(k_wf_primary, pgrid, block, 0, stream, sc, q, dead_b, stats);
+        else
+            launch_extend<0>(fs.instrumented, sc.wide != nullptr, !(sc.wide && sch.wide_levels <= q.lds_depth + 1u), sc.ext != 0,
+                             pgrid, stream, sc, q, b, dead_b, stats);
         if (wf.time_kernels) HIP_TRY(hipEventRecord(wf.ev[wf.ev_used + 1], stream));
         if (sc.ext) {
             if (pcg) hipLaunchKernelGGL((k_wf_shade<1, true>), sgrid, block, 0, stream, sc, f, q, b, (float4 *)wf.pass.ptr, accum_pixels, hit_ids);
