@@ -386,6 +386,10 @@ def main():
             kernel_name, kernel_bytes_per_ray = "k_wf_extend", node_b * V + 48.0 * T + 40.0
             n_launches = float(st.last_extend_launches) if not rebuild else float(st.last_extend_launches) * args.steps
             launch_ms = st.last_extend_ms / st.last_extend_launches
+            # bounce 0 runs in k_wf_primary (packets of primary rays) when the tree is 8-wide: its rays (one per path) and
+            # its time are not k_wf_extend's
+            if st.last_primary_launches:
+                rank_rays -= float(st.paths)
         else:
             kernel_name = "k_megakernel" if tracer == abi.TRACER_MEGAKERNEL else "k_wf_* (one render call, kernels not timed one by one)"
             kernel_bytes_per_ray = bytes_per_ray
@@ -416,6 +420,10 @@ def main():
         rl = kernel_roofline(kernel_name, pmc, launch_ms, launch_rays * kernel_bytes_per_ray)
         rl.update({"kernel_bytes_per_ray": round(kernel_bytes_per_ray, 1), "pipeline_bytes_per_ray": round(bytes_per_ray, 1),
                    "launches": int(n_launches), "rays_per_launch": round(launch_rays)})
+        if tracer == abi.TRACER_WAVEFRONT and st.last_primary_launches:
+            rl["primary"] = {"kernel": "k_wf_primary", "launches": int(st.last_primary_launches),
+                             "launch_ms": round(st.last_primary_ms / st.last_primary_launches, 4),
+                             "rays_per_launch": round(float(st.paths) / st.last_primary_launches)}
         if rl.get("valu_useful_frac") is not None:
             line["roofline"] = dict({"bound": "valu-issue", "achieved": rl["valu_Tlaneops"], "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlane-op/s",
                                      "frac": rl["valu_useful_frac"], "traffic": pmc.get("traffic")}, **rl)
@@ -430,7 +438,8 @@ def main():
             spmc = pmc_counters("k_wf_shade")
             shade_ms = st.last_shade_ms / st.last_shade_launches
             # k_wf_shade per path: 56 B queue entry + hit read, 64 B shading record, 48 B written per surviving path, 16 B per ended one
-            line["roofline"]["shade"] = kernel_roofline("k_wf_shade", spmc, shade_ms, launch_rays * (56.0 + 64.0 + 48.0 * (1.0 - 1.0 / D) + 16.0 / D))
+            shade_rays = float(st.rays) / st.last_shade_launches      # every bounce has a k_wf_shade, bounce 0 included
+            line["roofline"]["shade"] = kernel_roofline("k_wf_shade", spmc, shade_ms, shade_rays * (56.0 + 64.0 + 48.0 * (1.0 - 1.0 / D) + 16.0 / D))
         # BVH build against SURVEY 8(d)'s 376 B / primitive model
         n_prims = int(len(scene.tris) + len(scene.spheres) + len(scene.quads))
         line["build"] = {"ms": round(build_ms, 4), "prims": n_prims, "bytes_per_prim": 376,

@@ -71,7 +71,8 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64),
                 ("last_render_ms", C.c_double), ("last_build_ms", C.c_double), ("last_extend_ms", C.c_double),
-                ("last_extend_launches", C.c_uint64), ("last_shade_ms", C.c_double), ("last_shade_launches", C.c_uint64)]
+                ("last_extend_launches", C.c_uint64), ("last_shade_ms", C.c_double), ("last_shade_launches", C.c_uint64),
+                ("last_primary_ms", C.c_double), ("last_primary_launches", C.c_uint64)]
 
 
 class CrtError(RuntimeError):

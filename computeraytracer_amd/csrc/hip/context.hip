@@ -48,7 +48,8 @@ struct crt_context {
     GatherState gather;
     int instrumented = 0;
     double last_render_ms = 0.0, last_build_ms = 0.0, last_extend_ms = 0.0, last_shade_ms = 0.0;
-    uint64_t last_extend_launches = 0;
+    double last_primary_ms = 0.0;
+    uint64_t last_extend_launches = 0, last_shade_launches = 0, last_primary_launches = 0;
 };
 
 namespace {
@@ -168,12 +169,16 @@ int finish_timing(crt_context *ctx) {
         if (rc) return rc;
     }
     if (ctx->wf.ev_used) {
-        ctx->last_extend_ms = 0.0; ctx->last_shade_ms = 0.0; ctx->last_extend_launches = ctx->wf.ev_used / 3;
+        ctx->last_extend_ms = 0.0; ctx->last_shade_ms = 0.0; ctx->last_primary_ms = 0.0;
+        ctx->last_extend_launches = 0; ctx->last_primary_launches = 0; ctx->last_shade_launches = ctx->wf.ev_used / 3;
         for (size_t i = 0; i + 2 < ctx->wf.ev_used; i += 3) {
             float e = 0.0f, sh = 0.0f;
             CTX_HIP(hipEventElapsedTime(&e, ctx->wf.ev[i], ctx->wf.ev[i + 1]));
             CTX_HIP(hipEventElapsedTime(&sh, ctx->wf.ev[i + 1], ctx->wf.ev[i + 2]));
-            ctx->last_extend_ms += e; ctx->last_shade_ms += sh;
+            const bool primary = i / 3 < ctx->wf.ev_primary.size() && ctx->wf.ev_primary[i / 3];
+            if (primary) { ctx->last_primary_ms += e; ctx->last_primary_launches++; }
+            else { ctx->last_extend_ms += e; ctx->last_extend_launches++; }
+            ctx->last_shade_ms += sh;
         }
         ctx->wf.ev_used = 0;
     }
@@ -698,7 +703,8 @@ int crt_stats_read(crt_context *ctx, crt_stats *out) {
     out->rays = ds.rays; out->paths = ds.paths; out->node_visits = ds.node_visits; out->prim_tests = ds.prim_tests;
     out->last_render_ms = ctx->last_render_ms; out->last_build_ms = ctx->last_build_ms;
     out->last_extend_ms = ctx->last_extend_ms; out->last_extend_launches = ctx->last_extend_launches;
-    out->last_shade_ms = ctx->last_shade_ms; out->last_shade_launches = ctx->last_extend_launches;      // one k_wf_shade per k_wf_extend
+    out->last_shade_ms = ctx->last_shade_ms; out->last_shade_launches = ctx->last_shade_launches;
+    out->last_primary_ms = ctx->last_primary_ms; out->last_primary_launches = ctx->last_primary_launches;
     return CRT_OK;
 }
 

@@ -799,8 +799,9 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
         // bounce 0 over the 8-wide tree: tiles of primary rays as packets (k_wf_primary; 7 and 8 waves per SIMD measured slower
         // than 6).  The instrumented and the extension kernels stay per ray.
         static const bool env_primary = [] { const char *e = getenv("CRT_WF_PRIMARY"); return !e || atoi(e) != 0; }();
-        if (b == 0 && env_primary && sc.wide && !sc.ext && !fs.instrumented && sch.wide_levels <= kWideSpill)
-            hipLaunchKernelGGL(k_wf_primary, pgrid, block, 0, stream, sc, q, dead_b, stats);
+        const bool primary = b == 0 && env_primary && sc.wide && !sc.ext && !fs.instrumented && sch.wide_levels <= kWideSpill;
+        if (wf.time_kernels) { wf.ev_primary.resize(wf.ev_used / 3 + 1); wf.ev_primary[wf.ev_used / 3] = primary ? 1 : 0; }
+        if (primary) hipLaunchKernelGGL(k_wf_primary, pgrid, block, 0, stream, sc, q, dead_b, stats);
         else
             launch_extend<0>(fs.instrumented, sc.wide != nullptr, !(sc.wide && sch.wide_levels <= q.lds_depth + 1u), sc.ext != 0,
                              pgrid, stream, sc, q, b, dead_b, stats);

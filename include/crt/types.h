@@ -233,6 +233,9 @@ typedef struct crt_stats {
     uint64_t last_extend_launches;
     double   last_shade_ms;   /* the same for the k_wf_shade launches */
     uint64_t last_shade_launches;
+    double   last_primary_ms; /* the same for the k_wf_primary launches (bounce 0 over the 8-wide tree; their time and
+                                 launches are not part of last_extend_*) */
+    uint64_t last_primary_launches;
 } crt_stats;
 
 #ifdef __cplusplus
