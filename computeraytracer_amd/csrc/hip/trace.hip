@@ -431,7 +431,13 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
 // for all lanes at once.  A lane thus also tests boxes and primitives that its own traversal would have skipped: tests
 // that can only fail (a ray that hits a primitive enters every box around it), so hits and IDs are those of k_wf_extend.
 // Children are visited in the order of the packet's first ray's octant.
-__global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_primary(DeviceScene sc, WfQueues q, unsigned long long dead, DeviceStats *stats) {
+// A tile that looks at distant, dense geometry (the horizon of a 10 M-triangle terrain) is not coherent: its rays end in
+// hundreds of different leaves and the packet would visit the union of their paths (bounce 0 of config 5: three times
+// k_wf_extend's time).  A packet that has entered more than `max_visits` nodes therefore stops being one: its lanes keep
+// the hits they have and finish on their own, each with its own cursor and stack (the LaneTrav steps of k_wf_extend).
+constexpr uint32_t kPrimaryWaves = 5;      // 96 VGPRs with the per-lane fallback in the kernel; launched on k_wf_extend's grid all the same (6 blocks per CU: 1.3 % faster than 5)
+__global__ __launch_bounds__(256, kPrimaryWaves) void k_wf_primary(DeviceScene sc, WfQueues q, unsigned long long dead, uint32_t max_visits, DeviceStats *stats) {
+    __shared__ uint2 s_lane_stack[kWideLds * 256];
     __shared__ uint2 s_stack[4][kWideSpill + 2];
     __shared__ uint8_t s_order[kWideOrderBytes];
     wide_order_table(s_order, threadIdx.x, blockDim.x);
@@ -484,9 +490,11 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_primary(DeviceScen
         wide_begin(tr, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z));
         if (act != 0ull && sc.n_pairs != 0) {
             const uint32_t oct8 = (uint32_t)__builtin_amdgcn_readlane((int)tr.oct8, (int)__builtin_ctzll(act));
-            uint32_t cur = 0, g_hdr = 0, g_pend = 0, sp = 0;      // wave-uniform
+            uint32_t cur = 0, g_hdr = 0, g_pend = 0, sp = 0, visits = 0;      // wave-uniform
+            bool alone = false;
             for (;;) {
                 if (!(cur & kLeafTag)) {
+                    if (++visits > max_visits) { alone = true; break; }
                     const float4 *p = sc.wide + (size_t)kWideNodeF4 * cur;
                     const float4 h = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
                     const uint32_t m = active ? wide_test8(h, r1, r2, r3, tr.idir, tr.noid, tr.best_t * 1.000004f) : 0u;
@@ -514,6 +522,17 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_primary(DeviceScen
                 g_pend ^= bit;
                 if (imask & bit) cur = (g_hdr >> 8) + (uint32_t)__builtin_popcount(imask & (bit - 1u));
                 else cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.wide_links[(size_t)(g_pend >> 8) * 8u + sl]);
+            }
+            if (alone) {      // (as a separate, non-inlined function this costs 126 instead of 96 VGPRs)
+                LaneTrav<true, true> lt;
+                lt.tr = tr;
+                lt.tr.cur = 0; lt.tr.g_hdr = 0; lt.tr.g_pend = 0; lt.tr.sp = 0; lt.tr.tfar = tr.best_t * 1.000004f;
+                uint2 spill[kWideSpill];
+                Counts cnt = {0, 0};
+                bool more = active;
+                while (more) more = lt.at_leaf() ? lt.template leaf<false, false>(sc, s_order, s_lane_stack + threadIdx.x, spill, (int)q.lds_depth, cnt)
+                                                 : lt.template inner<false>(sc, s_order, s_lane_stack + threadIdx.x, spill, (int)q.lds_depth, cnt);
+                tr.best_t = lt.tr.best_t; tr.best_id = lt.tr.best_id;
             }
         }
         if (in_pool) q.hit[slot] = make_uint2(f2u(tr.best_t), tr.best_id);
@@ -801,7 +820,8 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
         static const bool env_primary = [] { const char *e = getenv("CRT_WF_PRIMARY"); return !e || atoi(e) != 0; }();
         const bool primary = b == 0 && env_primary && sc.wide && !sc.ext && !fs.instrumented && sch.wide_levels <= kWideSpill;
         if (wf.time_kernels) { wf.ev_primary.resize(wf.ev_used / 3 + 1); wf.ev_primary[wf.ev_used / 3] = primary ? 1 : 0; }
-        if (primary) hipLaunchKernelGGL(k_wf_primary, pgrid, block, 0, stream, sc, q, dead_b, stats);
+        static const uint32_t env_packet_visits = [] { const char *e = getenv("CRT_WF_PACKET_VISITS"); return (uint32_t)(e ? atoi(e) : 32); }();
+        if (primary) hipLaunchKernelGGL(k_wf_primary, pgrid, block, 0, stream, sc, q, dead_b, env_packet_visits, stats);
         else
             launch_extend<0>(fs.instrumented, sc.wide != nullptr, !(sc.wide && sch.wide_levels <= q.lds_depth + 1u), sc.ext != 0,
                              pgrid, stream, sc, q, b, dead_b, stats);
