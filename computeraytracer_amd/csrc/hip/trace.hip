@@ -424,6 +424,8 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
     }
 }
 
+extern "C" __device__ uint32_t __ockl_wfred_or_u32(uint32_t);      // OR over the wave (ROCm device library)
+
 // Bounce 0 of the 8-wide tree as PACKETS: the 64 primary rays of a queue batch are the 8 x 8 pixels of one tile, so they
 // walk nearly the same nodes.  The wave keeps ONE cursor and ONE stack for all of them (wave-uniform values: scalar
 // registers, scalar branches, one memory request per node instead of up to 64); a node is entered when ANY lane's ray
@@ -498,9 +500,7 @@ __global__ __launch_bounds__(256, kPrimaryWaves) void k_wf_primary(DeviceScene s
                     const float4 *p = sc.wide + (size_t)kWideNodeF4 * cur;
                     const float4 h = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
                     const uint32_t m = active ? wide_test8(h, r1, r2, r3, tr.idir, tr.noid, tr.best_t * 1.000004f) : 0u;
-                    uint32_t any = 0;
-#pragma unroll
-                    for (uint32_t sl = 0; sl < 8; sl++) if (__ballot((m >> sl) & 1u) != 0ull) any |= 1u << sl;
+                    const uint32_t any = (uint32_t)__builtin_amdgcn_readfirstlane((int)__ockl_wfred_or_u32(m));      // DPP reduction: 8 ballots cost twice as much
                     if (any != 0u) {
                         if ((g_pend & 0xFFu) != 0u) { if (lane == 0) stack[sp] = make_uint2(g_hdr, g_pend); sp++; }
                         g_hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(h.w));
