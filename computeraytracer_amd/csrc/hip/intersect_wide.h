@@ -87,7 +87,14 @@ CRT_DEV f32x2 splat2(float v) { f32x2 r; r.x = v; r.y = v; return r; }
 CRT_DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }        // v_pk_fma_f32
 
 // The eight slab tests of one node (its four 16-byte rows) for one ray: hit mask, bit = slot.
+CRT_DEV uint32_t wide_test8(float4 h, float4 r1, float4 r2, float4 r3, V3 idir, V3 noid, float tfar, bool nx, bool ny, bool nz);
 CRT_DEV uint32_t wide_test8(float4 h, float4 r1, float4 r2, float4 r3, V3 idir, V3 noid, float tfar) {
+    // near planes are the low ones for a non-negative direction component, the high ones otherwise
+    return wide_test8(h, r1, r2, r3, idir, noid, tfar, (int32_t)f2u(idir.x) < 0, (int32_t)f2u(idir.y) < 0, (int32_t)f2u(idir.z) < 0);
+}
+// nx, ny, nz: the direction component is negative (k_wf_primary passes wave-uniform values when the whole packet shares
+// an octant: the twelve selects below are scalar then)
+CRT_DEV uint32_t wide_test8(float4 h, float4 r1, float4 r2, float4 r3, V3 idir, V3 noid, float tfar, bool nx, bool ny, bool nz) {
     const uint32_t hx = f2u(h.x), hy = f2u(h.y), hz = f2u(h.z);
     constexpr float kErr = 4.76837158203125e-07f;      // 2^-21
     // per-axis plane coefficients: t_near = q * a + bn, t_far = q * a + bf.  Bit 8 of a header word is zero, so
@@ -103,8 +110,6 @@ CRT_DEV uint32_t wide_test8(float4 h, float4 r1, float4 r2, float4 r3, V3 idir, 
     const f32x2 ax2 = splat2(ax), ay2 = splat2(ay), az2 = splat2(az);
     const f32x2 bnx = splat2(bx - ex), bny = splat2(by - ey), bnz = splat2(bz - ez);
     const f32x2 bfx = splat2(bx + ex), bfy = splat2(by + ey), bfz = splat2(bz + ez);
-    // near planes are the low ones for a non-negative direction component, the high ones otherwise
-    const bool nx = (int32_t)f2u(idir.x) < 0, ny = (int32_t)f2u(idir.y) < 0, nz = (int32_t)f2u(idir.z) < 0;
     const uint32_t lox[2] = {f2u(r1.x), f2u(r1.y)}, loy[2] = {f2u(r1.z), f2u(r1.w)}, loz[2] = {f2u(r2.x), f2u(r2.y)};
     const uint32_t hix[2] = {f2u(r2.z), f2u(r2.w)}, hiy[2] = {f2u(r3.x), f2u(r3.y)}, hiz[2] = {f2u(r3.z), f2u(r3.w)};
     uint32_t m = 0;

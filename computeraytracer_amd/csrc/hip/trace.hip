@@ -492,6 +492,8 @@ __global__ __launch_bounds__(256, kPrimaryWaves) void k_wf_primary(DeviceScene s
         wide_begin(tr, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z));
         if (act != 0ull && sc.n_pairs != 0) {
             const uint32_t oct8 = (uint32_t)__builtin_amdgcn_readlane((int)tr.oct8, (int)__builtin_ctzll(act));
+            const bool one_octant = __ballot(active && tr.oct8 != oct8) == 0ull;
+            const bool unx = (oct8 >> 8) & 1u, uny = (oct8 >> 9) & 1u, unz = (oct8 >> 10) & 1u;
             uint32_t cur = 0, g_hdr = 0, g_pend = 0, sp = 0, visits = 0;      // wave-uniform
             bool alone = false;
             for (;;) {
@@ -499,7 +501,9 @@ __global__ __launch_bounds__(256, kPrimaryWaves) void k_wf_primary(DeviceScene s
                     if (++visits > max_visits) { alone = true; break; }
                     const float4 *p = sc.wide + (size_t)kWideNodeF4 * cur;
                     const float4 h = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
-                    const uint32_t m = active ? wide_test8(h, r1, r2, r3, tr.idir, tr.noid, tr.best_t * 1.000004f) : 0u;
+                    uint32_t m = 0u;
+                    if (one_octant) { if (active) m = wide_test8(h, r1, r2, r3, tr.idir, tr.noid, tr.best_t * 1.000004f, unx, uny, unz); }
+                    else if (active) m = wide_test8(h, r1, r2, r3, tr.idir, tr.noid, tr.best_t * 1.000004f);
                     const uint32_t any = (uint32_t)__builtin_amdgcn_readfirstlane((int)__ockl_wfred_or_u32(m));      // DPP reduction: 8 ballots cost twice as much
                     if (any != 0u) {
                         if ((g_pend & 0xFFu) != 0u) { if (lane == 0) stack[sp] = make_uint2(g_hdr, g_pend); sp++; }
