@@ -421,7 +421,8 @@ def main():
         rl.update({"kernel_bytes_per_ray": round(kernel_bytes_per_ray, 1), "pipeline_bytes_per_ray": round(bytes_per_ray, 1),
                    "launches": int(n_launches), "rays_per_launch": round(launch_rays)})
         if tracer == abi.TRACER_WAVEFRONT and st.last_primary_launches:
-            rl["primary"] = {"kernel": "k_wf_primary", "launches": int(st.last_primary_launches),
+            rl["primary"] = {"kernel": "k_wf_primary" + (" (rays, traversal and shading of bounce 0)" if st.last_shade_launches == st.last_extend_launches else ""),
+                             "launches": int(st.last_primary_launches),
                              "launch_ms": round(st.last_primary_ms / st.last_primary_launches, 4),
                              "rays_per_launch": round(float(st.paths) / st.last_primary_launches)}
         if rl.get("valu_useful_frac") is not None:
@@ -438,7 +439,10 @@ def main():
             spmc = pmc_counters("k_wf_shade")
             shade_ms = st.last_shade_ms / st.last_shade_launches
             # k_wf_shade per path: 56 B queue entry + hit read, 64 B shading record, 48 B written per surviving path, 16 B per ended one
-            shade_rays = float(st.rays) / st.last_shade_launches      # every bounce has a k_wf_shade, bounce 0 included
+            # every bounce has a k_wf_shade, except bounce 0 when k_wf_primary runs the whole first bounce (then there are as many
+            # k_wf_shade launches as k_wf_extend launches and the primary rays are not theirs)
+            fused_first = st.last_primary_launches and st.last_shade_launches == st.last_extend_launches
+            shade_rays = (float(st.rays) - (float(st.paths) if fused_first else 0.0)) / st.last_shade_launches
             line["roofline"]["shade"] = kernel_roofline("k_wf_shade", spmc, shade_ms, shade_rays * (56.0 + 64.0 + 48.0 * (1.0 - 1.0 / D) + 16.0 / D))
         # BVH build against SURVEY 8(d)'s 376 B / primitive model
         n_prims = int(len(scene.tris) + len(scene.spheres) + len(scene.quads))

@@ -102,7 +102,7 @@ struct WavefrontState {
     int tail_bounce = -1;            // >= 0: this dispatch ends in k_wf_tail from that bounce on (set per dispatch by the context, trace.hip)
     std::vector<hipEvent_t> ev;      // per bounce: before k_wf_extend, between it and k_wf_shade, after k_wf_shade
     size_t ev_used = 0;
-    std::vector<uint8_t> ev_primary; // per bounce recorded: 1 = the first kernel was k_wf_primary, not k_wf_extend
+    std::vector<uint8_t> ev_primary; // per bounce recorded: 1 = the first kernel was k_wf_primary, not k_wf_extend; 2 = k_wf_primary ran the whole bounce (no k_wf_shade)
 };
 
 bool launch_megakernel(hipStream_t stream, const DeviceSceneHost &sc, const FrameSetup &fs, const crt_scene_params &params,

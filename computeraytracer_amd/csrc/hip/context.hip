@@ -170,15 +170,15 @@ int finish_timing(crt_context *ctx) {
     }
     if (ctx->wf.ev_used) {
         ctx->last_extend_ms = 0.0; ctx->last_shade_ms = 0.0; ctx->last_primary_ms = 0.0;
-        ctx->last_extend_launches = 0; ctx->last_primary_launches = 0; ctx->last_shade_launches = ctx->wf.ev_used / 3;
+        ctx->last_extend_launches = 0; ctx->last_primary_launches = 0; ctx->last_shade_launches = 0;
         for (size_t i = 0; i + 2 < ctx->wf.ev_used; i += 3) {
             float e = 0.0f, sh = 0.0f;
             CTX_HIP(hipEventElapsedTime(&e, ctx->wf.ev[i], ctx->wf.ev[i + 1]));
             CTX_HIP(hipEventElapsedTime(&sh, ctx->wf.ev[i + 1], ctx->wf.ev[i + 2]));
-            const bool primary = i / 3 < ctx->wf.ev_primary.size() && ctx->wf.ev_primary[i / 3];
+            const int primary = i / 3 < ctx->wf.ev_primary.size() ? ctx->wf.ev_primary[i / 3] : 0;
             if (primary) { ctx->last_primary_ms += e; ctx->last_primary_launches++; }
             else { ctx->last_extend_ms += e; ctx->last_extend_launches++; }
-            ctx->last_shade_ms += sh;
+            if (primary != 2) { ctx->last_shade_ms += sh; ctx->last_shade_launches++; }
         }
         ctx->wf.ev_used = 0;
     }

@@ -438,7 +438,17 @@ extern "C" __device__ uint32_t __ockl_wfred_or_u32(uint32_t);      // OR over th
 // k_wf_extend's time).  A packet that has entered more than `max_visits` nodes therefore stops being one: its lanes keep
 // the hits they have and finish on their own, each with its own cursor and stack (the LaneTrav steps of k_wf_extend).
 constexpr uint32_t kPrimaryWaves = 5;      // 96 VGPRs with the per-lane fallback in the kernel; launched on k_wf_extend's grid all the same (6 blocks per CU: 1.3 % faster than 5)
-__global__ __launch_bounds__(256, kPrimaryWaves) void k_wf_primary(DeviceScene sc, WfQueues q, unsigned long long dead, uint32_t max_visits, DeviceStats *stats) {
+// FIRST = 0: rays from the bounce-0 queue (k_wf_generate), hit records for k_wf_shade.  FIRST = 1 + RNG mode: the whole
+// first bounce in this kernel: the wave makes its tile's camera rays itself (k_wf_generate's code), traces them and
+// shades them (k_wf_shade's code) while they are in registers, and writes the survivors straight into the bounce-1 queue.
+// No bounce-0 queue, no hit records, two launches fewer: 80 bytes per path that are never written and 56 that are never
+// read back (the rays, their hit records), of the ~290 the first bounce moved.  `count` = dead lanes (FIRST = 0) or paths.
+#ifndef CRT_FIRST_WAVES
+#define CRT_FIRST_WAVES 5
+#endif
+template <int FIRST>
+__global__ __launch_bounds__(256, (FIRST ? CRT_FIRST_WAVES : kPrimaryWaves)) void k_wf_primary(DeviceScene sc, Frame f, WfQueues q, unsigned long long count, uint32_t max_visits,
+                                                                    float4 *pass_buf, uint32_t pass_stride, uint32_t *hit_ids, DeviceStats *stats) {
     __shared__ uint2 s_lane_stack[kWideLds * 256];
     __shared__ uint4 s_stack[4][kWideSpill + 2];      // group header, pending mask, epoch
     __shared__ uint8_t s_order[kWideOrderBytes];
@@ -449,14 +459,17 @@ __global__ __launch_bounds__(256, kPrimaryWaves) void k_wf_primary(DeviceScene s
     uint32_t *cursors = q.cursors;
     const float4 *ro = q.ray_o[0], *rd = q.ray_d[0];
     if (blockIdx.x == 0) {
-        unsigned long long n = wave_sum(threadIdx.x < kShards ? (unsigned long long)counts[threadIdx.x * kCtrStride] : 0ull);
-        if (lane == 0) atomicAdd(&stats->rays, n - (wave == 0 ? dead : 0ull));
+        if (FIRST) { if (threadIdx.x == 0) atomicAdd(&stats->rays, count); }
+        else {
+            unsigned long long n = wave_sum(threadIdx.x < kShards ? (unsigned long long)counts[threadIdx.x * kCtrStride] : 0ull);
+            if (lane == 0) atomicAdd(&stats->rays, n - (wave == 0 ? count : 0ull));
+        }
     }
     const uint32_t ns = q.n_shards, per = ns >= 8 ? ns / 8 : 1;
     const uint32_t home = home_shard(blockIdx.x, wave, ns);
     const uint32_t waves_here = max(1u, (gridDim.x * 4u) / ns);
     uint4 *stack = s_stack[wave];
-    uint32_t k = 0, pool_next = 0, pool_end = 0, pool_base = 0;
+    uint32_t k = 0, pool_next = 0, pool_end = 0, pool_base = 0, pool_shard = 0;
     for (;;) {
         if (pool_next >= pool_end) {
             while (k < ns) {
@@ -468,7 +481,7 @@ __global__ __launch_bounds__(256, kPrimaryWaves) void k_wf_primary(DeviceScene s
                     uint32_t *cursor = cursors + s * kCtrStride;
                     if (lane == 0 && *(volatile uint32_t *)cursor < n) base = atomicAdd(cursor, 64u * fetch);
                     base = __shfl(base, 0);
-                    if (base < n) { pool_base = s * q.shard_cap; pool_next = base; pool_end = min(n, base + 64u * fetch); break; }
+                    if (base < n) { pool_base = s * q.shard_cap; pool_shard = s; pool_next = base; pool_end = min(n, base + 64u * fetch); break; }
                 }
                 k++;
                 {
@@ -485,11 +498,31 @@ __global__ __launch_bounds__(256, kPrimaryWaves) void k_wf_primary(DeviceScene s
         pool_next = min(pool_end, pool_next + 64u);
         const bool in_pool = i < pool_end;
         const uint32_t slot = pool_base + (in_pool ? i : pool_end - 1u);
-        const float4 o4 = ro[slot], d4 = rd[slot];
-        const bool active = in_pool && f2u(d4.w) != kDeadPixel;
+        bool active;
+        V3 o, d;
+        uint32_t pix = 0, it = 0;
+        Rng<(FIRST > 1 ? 1 : 0)> rng;
+        if constexpr (FIRST != 0) {
+            // queue slot -> virtual tile (iteration-major over the batch) -> pixel -> camera ray: k_wf_generate's code (main(), compute.comp:460-468)
+            const uint32_t vt = pool_shard * q.tiles_per_shard + (i >> 6);
+            it = vt / f.n_tiles;
+            const uint32_t tile = vt - it * f.n_tiles;
+            uint32_t x = 0, y = 0, prow = 0;
+            active = in_pool && vt < f.n_tiles * f.n_batch && tile_pixel(f, tile, i & 63u, x, y, prow);
+            pix = prow * f.width + x;
+            const crt_camera_data &cam = f.p.camera;
+            rng.init(f.seeds[it < kBatchMax ? it : 0], x, y, y * f.width + x, f.iter0 + (float)it);
+            float ox, oy; hash_2(rng, ox, oy);
+            const float u = ((float)x + ox) / (float)f.width, v = ((float)y + oy) / (float)f.height;
+            camera_get_ray(cam, u, v, rng, o, d);
+        } else {
+            const float4 o4 = ro[slot], d4 = rd[slot];
+            active = in_pool && f2u(d4.w) != kDeadPixel;
+            o = mk3(o4.x, o4.y, o4.z); d = mk3(d4.x, d4.y, d4.z);
+        }
         const unsigned long long act = __ballot(active);
         WideTrav tr;
-        wide_begin(tr, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z));
+        wide_begin(tr, o, d);
         if (act != 0ull && sc.n_pairs != 0) {
             const uint32_t oct8 = (uint32_t)__builtin_amdgcn_readlane((int)tr.oct8, (int)__builtin_ctzll(act));
             const bool one_octant = __ballot(active && tr.oct8 != oct8) == 0ull;
@@ -559,7 +592,40 @@ __global__ __launch_bounds__(256, kPrimaryWaves) void k_wf_primary(DeviceScene s
                 tr.best_t = lt.tr.best_t; tr.best_id = lt.tr.best_id;
             }
         }
-        if (in_pool) q.hit[slot] = make_uint2(f2u(tr.best_t), tr.best_id);
+        if constexpr (FIRST == 0) { if (in_pool) q.hit[slot] = make_uint2(f2u(tr.best_t), tr.best_id); }
+        else {
+            // k_wf_shade's body for bounce 0 (every lane takes part in the triangle-record fetch)
+            constexpr int RNGM = FIRST > 1 ? 1 : 0;
+            const uint32_t id = tr.best_id;
+            if (active && it + 1 == f.n_batch) hit_ids[pix] = id;
+            TriRec trec = {make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
+            if (sc.n_tris != 0u) trec = tri_rec_quad_fetch(sc.tri_shade, (active && (id >> 30) == CRT_ID_KIND_TRI) ? (id & 0x3FFFFFFFu) : 0u, lane);
+            bool alive = false;
+            V3 color = mk3(1.0f, 1.0f, 1.0f);
+            if (active) {
+                V3 emitted = mk3(0.0f, 0.0f, 0.0f), pass = mk3(0.0f, 0.0f, 0.0f);
+                if (id == kIdMiss) pass = shade_miss(f.p, d, color);
+                else alive = shade_hit<RNGM, false, true>(sc, o, d, tr.best_t, id, rng, color, emitted, pass, trec);
+                if (alive && 1u >= f.max_bounces) { alive = false; pass = mk3(0.0f, 0.0f, 0.0f); }
+                if (!alive) {
+                    pass = pass * (1.0f / 1.0f);
+                    pass_buf[(size_t)it * pass_stride + pix] = make_float4(pass.x, pass.y, pass.z, 0.0f);
+                }
+            }
+            const unsigned long long mask = __ballot(alive);
+            if (mask != 0ull) {
+                uint32_t obase = 0;
+                if (lane == 0) obase = atomicAdd(q.counts + (kShards + pool_shard) * kCtrStride, (uint32_t)__popcll(mask));
+                obase = __shfl(obase, 0);
+                if (alive) {
+                    const uint32_t os = pool_shard * q.shard_cap + obase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                    const uint64_t rs = rng.pack();
+                    q.ray_o[1][os] = make_float4(o.x, o.y, o.z, u2f((uint32_t)rs));
+                    q.ray_d[1][os] = make_float4(d.x, d.y, d.z, u2f((it << kPixBits) | pix));
+                    q.thr[1][os] = make_float4(color.x, color.y, color.z, u2f((uint32_t)(rs >> 32)));
+                }
+            }
+        }
     }
 }
 
@@ -812,7 +878,16 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     const dim3 sgrid(env_sgrid ? env_sgrid : nb);
     const bool pcg = fs.rng_mode != CRT_RNG_REF;
     hipLaunchKernelGGL(k_wf_init, dim3(1), dim3(256), 0, stream, q, n_vt, n_active, stats);
-    if (pcg) hipLaunchKernelGGL((k_wf_generate<1>), gen_grid, block, 0, stream, sc, f, q, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
+    // Bounce 0 over the 8-wide tree: tiles of primary rays as packets (k_wf_primary).  The instrumented and the extension
+    // kernels stay per ray.  Unless something needs the bounce-0 queue (the outline debug view, which k_wf_generate draws;
+    // the path kernel from bounce 0), the packet kernel runs the whole first bounce: rays, traversal, shading.
+    static const bool env_primary = [] { const char *e = getenv("CRT_WF_PRIMARY"); return !e || atoi(e) != 0; }();
+    static const bool env_first = [] { const char *e = getenv("CRT_WF_FIRST"); return !e || atoi(e) != 0; }();
+    static const uint32_t env_packet_visits = [] { const char *e = getenv("CRT_WF_PACKET_VISITS"); return (uint32_t)(e ? atoi(e) : 32); }();
+    const bool packets = env_primary && sc.wide && !sc.ext && !fs.instrumented && sch.wide_levels <= kWideSpill && wf.tail_bounce != 0;
+    const bool first_bounce = packets && env_first && params.camera.shouldRenderAABB == 0u;
+    if (first_bounce) {}
+    else if (pcg) hipLaunchKernelGGL((k_wf_generate<1>), gen_grid, block, 0, stream, sc, f, q, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
     else hipLaunchKernelGGL((k_wf_generate<0>), gen_grid, block, 0, stream, sc, f, q, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
     // small batches finish in k_wf_tail from this bounce on (0: never)
     for (uint32_t b = 0; b < f.max_bounces; b++) {
@@ -839,13 +914,15 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
         }
         q.lds_depth = fs.small_stack ? 1u : (sc.wide ? (uint32_t)kWideLds : (uint32_t)kLdsStack);
         // wide trees of at most lds_depth + 1 levels never overflow the LDS stack (at most levels - 1 groups wait on it)
-        // bounce 0 over the 8-wide tree: tiles of primary rays as packets (k_wf_primary; 7 and 8 waves per SIMD measured slower
-        // than 6).  The instrumented and the extension kernels stay per ray.
-        static const bool env_primary = [] { const char *e = getenv("CRT_WF_PRIMARY"); return !e || atoi(e) != 0; }();
-        const bool primary = b == 0 && env_primary && sc.wide && !sc.ext && !fs.instrumented && sch.wide_levels <= kWideSpill;
-        if (wf.time_kernels) { wf.ev_primary.resize(wf.ev_used / 3 + 1); wf.ev_primary[wf.ev_used / 3] = primary ? 1 : 0; }
-        static const uint32_t env_packet_visits = [] { const char *e = getenv("CRT_WF_PACKET_VISITS"); return (uint32_t)(e ? atoi(e) : 32); }();
-        if (primary) hipLaunchKernelGGL(k_wf_primary, pgrid, block, 0, stream, sc, q, dead_b, env_packet_visits, stats);
+        const bool primary = b == 0 && packets;
+        if (wf.time_kernels) { wf.ev_primary.resize(wf.ev_used / 3 + 1); wf.ev_primary[wf.ev_used / 3] = primary ? (first_bounce ? 2 : 1) : 0; }      // 2: no k_wf_shade behind it
+        if (primary && first_bounce) {
+            if (pcg) hipLaunchKernelGGL(k_wf_primary<2>, pgrid, block, 0, stream, sc, f, q, n_active, env_packet_visits, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
+            else hipLaunchKernelGGL(k_wf_primary<1>, pgrid, block, 0, stream, sc, f, q, n_active, env_packet_visits, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
+            if (wf.time_kernels) { HIP_TRY(hipEventRecord(wf.ev[wf.ev_used + 1], stream)); HIP_TRY(hipEventRecord(wf.ev[wf.ev_used + 2], stream)); wf.ev_used += 3; }
+            continue;      // no k_wf_shade for this bounce
+        }
+        if (primary) hipLaunchKernelGGL(k_wf_primary<0>, pgrid, block, 0, stream, sc, f, q, dead_b, env_packet_visits, (float4 *)nullptr, 0u, (uint32_t *)nullptr, stats);
         else
             launch_extend<0>(fs.instrumented, sc.wide != nullptr, !(sc.wide && sch.wide_levels <= q.lds_depth + 1u), sc.ext != 0,
                              pgrid, stream, sc, q, b, dead_b, stats);
