@@ -886,9 +886,10 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     static const uint32_t env_packet_visits = [] { const char *e = getenv("CRT_WF_PACKET_VISITS"); return (uint32_t)(e ? atoi(e) : 32); }();
     const bool packets = env_primary && sc.wide && !sc.ext && !fs.instrumented && sch.wide_levels <= kWideSpill && wf.tail_bounce != 0;
     const bool first_bounce = packets && env_first && params.camera.shouldRenderAABB == 0u;
-    if (first_bounce) {}
-    else if (pcg) hipLaunchKernelGGL((k_wf_generate<1>), gen_grid, block, 0, stream, sc, f, q, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
-    else hipLaunchKernelGGL((k_wf_generate<0>), gen_grid, block, 0, stream, sc, f, q, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
+    if (!first_bounce) {
+        if (pcg) hipLaunchKernelGGL((k_wf_generate<1>), gen_grid, block, 0, stream, sc, f, q, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
+        else hipLaunchKernelGGL((k_wf_generate<0>), gen_grid, block, 0, stream, sc, f, q, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
+    }
     // small batches finish in k_wf_tail from this bounce on (0: never)
     for (uint32_t b = 0; b < f.max_bounces; b++) {
         if (wf.tail_bounce >= 0 && b == (uint32_t)wf.tail_bounce) {      // small batches: the context decides (crt_context::TailTune)
