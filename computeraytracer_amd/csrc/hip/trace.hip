@@ -710,7 +710,8 @@ __global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene s
 // kernel takes the survivors of bounce `bounce0` and runs each path to its end, one lane per path: traversal (the same
 // LaneTrav steps, without the wave-level phases) and shade_hit in a loop, no queue traffic in between.  Same functions,
 // same order of RNG draws per path as the per-bounce kernels: the image is bit-identical.
-template <int RNGM, bool WIDE, bool SPILL, bool EXT>
+// GEN (bounce0 == 0, no outline view): the lane makes its camera ray itself instead of reading k_wf_generate's queue entry.
+template <int RNGM, bool WIDE, bool SPILL, bool EXT, bool GEN = false>
 __global__ __launch_bounds__(256) void k_wf_tail(DeviceScene sc, Frame f, WfQueues q, uint32_t bounce0, unsigned long long dead, float4 *pass_buf, uint32_t pass_stride, uint32_t *hit_ids, DeviceStats *stats) {
     __shared__ uint2 s_stack[kWideLds * 256];
     __shared__ uint8_t s_order[WIDE ? kWideOrderBytes : 4];
@@ -725,15 +726,30 @@ __global__ __launch_bounds__(256) void k_wf_tail(DeviceScene sc, Frame f, WfQueu
     unsigned long long rays = 0;
     if (s < q.n_shards && i < q.counts[(bounce0 * kShards + s) * kCtrStride]) {
         const uint32_t slot = s * q.shard_cap + i;
-        const float4 o4 = q.ray_o[in][slot], d4 = q.ray_d[in][slot];
-        float4 c4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);      // what k_wf_generate would have stored (see there)
-        if (RNGM != 0 || bounce0 != 0) c4 = q.thr[in][slot];
-        V3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z), color = mk3(c4.x, c4.y, c4.z);
-        uint32_t pix = f2u(d4.w), it = 0;
-        if (pix != kDeadPixel) {      // (a lane outside the rendered grid: bounce 0 only)
-        if (f.n_batch > 1) { it = pix >> kPixBits; pix &= (1u << kPixBits) - 1u; }
+        V3 o, d, color = mk3(1.0f, 1.0f, 1.0f);
+        uint32_t pix = kDeadPixel, it = 0;
         Rng<RNGM> rng;
-        rng.unpack((uint64_t)f2u(o4.w) | ((uint64_t)f2u(c4.w) << 32), ((uint64_t)(uint32_t)(f.iter0 + (float)it) << 1) | 1u);
+        if constexpr (GEN) {
+            // queue slot -> virtual tile -> pixel -> camera ray (k_wf_generate's code)
+            const uint32_t vt = s * q.tiles_per_shard + (i >> 6);
+            it = vt / f.n_tiles;
+            uint32_t x = 0, y = 0, prow = 0;
+            const bool active = vt < f.n_tiles * f.n_batch && tile_pixel(f, vt - it * f.n_tiles, i & 63u, x, y, prow);
+            rng.init(f.seeds[it < kBatchMax ? it : 0], x, y, y * f.width + x, f.iter0 + (float)it);
+            float ox, oy; hash_2(rng, ox, oy);
+            const float u = ((float)x + ox) / (float)f.width, v = ((float)y + oy) / (float)f.height;
+            camera_get_ray(f.p.camera, u, v, rng, o, d);
+            if (active) pix = prow * f.width + x;
+        } else {
+            const float4 o4 = q.ray_o[in][slot], d4 = q.ray_d[in][slot];
+            float4 c4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);      // what k_wf_generate would have stored (see there)
+            if (RNGM != 0 || bounce0 != 0) c4 = q.thr[in][slot];
+            o = mk3(o4.x, o4.y, o4.z); d = mk3(d4.x, d4.y, d4.z); color = mk3(c4.x, c4.y, c4.z);
+            pix = f2u(d4.w);
+            if (pix != kDeadPixel && f.n_batch > 1) { it = pix >> kPixBits; pix &= (1u << kPixBits) - 1u; }
+            rng.unpack((uint64_t)f2u(o4.w) | ((uint64_t)f2u(c4.w) << 32), ((uint64_t)(uint32_t)(f.iter0 + (float)it) << 1) | 1u);
+        }
+        if (pix != kDeadPixel) {      // (a lane outside the rendered grid: bounce 0 only)
         using LT = LaneTrav<WIDE, SPILL>;
         typename LT::Entry spill[LT::kSpill];
         typename LT::Entry *stack = (typename LT::Entry *)s_stack + threadIdx.x;
@@ -886,7 +902,8 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     static const uint32_t env_packet_visits = [] { const char *e = getenv("CRT_WF_PACKET_VISITS"); return (uint32_t)(e ? atoi(e) : 32); }();
     const bool packets = env_primary && sc.wide && !sc.ext && !fs.instrumented && sch.wide_levels <= kWideSpill && wf.tail_bounce != 0;
     const bool first_bounce = packets && env_first && params.camera.shouldRenderAABB == 0u;
-    if (!first_bounce) {
+    const bool gen_in_tail = wf.tail_bounce == 0 && env_first && params.camera.shouldRenderAABB == 0u;      // the path kernel makes its own camera rays
+    if (!first_bounce && !gen_in_tail) {
         if (pcg) hipLaunchKernelGGL((k_wf_generate<1>), gen_grid, block, 0, stream, sc, f, q, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
         else hipLaunchKernelGGL((k_wf_generate<0>), gen_grid, block, 0, stream, sc, f, q, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
     }
@@ -897,7 +914,16 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
             const bool wide = sc.wide != nullptr, spill = sc.ext != 0 || !(wide && sch.wide_levels <= q.lds_depth + 1u);
             const dim3 tgrid((cap + 255) / 256);
             const int variant = (pcg ? 8 : 0) | (wide ? 4 : 0) | (spill ? 2 : 0) | (sc.ext ? 1 : 0);
-            switch (variant) {
+            if (gen_in_tail) switch (variant) {
+#define CRT_TAIL_CASE(V, R, W, S, A) case V: hipLaunchKernelGGL((k_wf_tail<R, W, S, A, true>), tgrid, block, 0, stream, sc, f, q, b, dead, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats); break;
+                CRT_TAIL_CASE(2, 0, false, true, false)  CRT_TAIL_CASE(3, 0, false, true, true)
+                CRT_TAIL_CASE(4, 0, true, false, false)  CRT_TAIL_CASE(6, 0, true, true, false)  CRT_TAIL_CASE(7, 0, true, true, true)
+                CRT_TAIL_CASE(10, 1, false, true, false)  CRT_TAIL_CASE(11, 1, false, true, true)
+                CRT_TAIL_CASE(12, 1, true, false, false)  CRT_TAIL_CASE(14, 1, true, true, false)  CRT_TAIL_CASE(15, 1, true, true, true)
+#undef CRT_TAIL_CASE
+                default: break;
+            }
+            else switch (variant) {
 #define CRT_TAIL_CASE(V, R, W, S, A) case V: hipLaunchKernelGGL((k_wf_tail<R, W, S, A>), tgrid, block, 0, stream, sc, f, q, b, b == 0 ? dead : 0ull, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats); break;
                 CRT_TAIL_CASE(2, 0, false, true, false)  CRT_TAIL_CASE(3, 0, false, true, true)
                 CRT_TAIL_CASE(4, 0, true, false, false)  CRT_TAIL_CASE(6, 0, true, true, false)  CRT_TAIL_CASE(7, 0, true, true, true)
