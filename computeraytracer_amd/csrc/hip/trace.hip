@@ -712,7 +712,9 @@ __global__ __launch_bounds__(256, CRT_SHADE_WAVES) void k_wf_shade(DeviceScene s
 // same order of RNG draws per path as the per-bounce kernels: the image is bit-identical.
 // GEN (bounce0 == 0, no outline view): the lane makes its camera ray itself instead of reading k_wf_generate's queue entry.
 template <int RNGM, bool WIDE, bool SPILL, bool EXT, bool GEN = false>
-__global__ __launch_bounds__(256) void k_wf_tail(DeviceScene sc, Frame f, WfQueues q, uint32_t bounce0, unsigned long long dead, float4 *pass_buf, uint32_t pass_stride, uint32_t *hit_ids, DeviceStats *stats) {
+// accum != nullptr (GEN, one iteration): the path's radiance goes straight into the accumulation image (main(), compute.comp:470-476:
+// every pixel has exactly one path), no radiance slot and no k_wf_accumulate launch.
+__global__ __launch_bounds__(256) void k_wf_tail(DeviceScene sc, Frame f, WfQueues q, uint32_t bounce0, unsigned long long dead, float4 *pass_buf, uint32_t pass_stride, uint32_t *hit_ids, float4 *accum, DeviceStats *stats) {
     __shared__ uint2 s_stack[kWideLds * 256];
     __shared__ uint8_t s_order[WIDE ? kWideOrderBytes : 4];
     if (WIDE) { wide_order_table(s_order, threadIdx.x, blockDim.x); __syncthreads(); }
@@ -773,7 +775,11 @@ __global__ __launch_bounds__(256) void k_wf_tail(DeviceScene sc, Frame f, WfQueu
             if (!alive) break;
         }
         pass = pass * (1.0f / 1.0f);
-        pass_buf[(size_t)it * pass_stride + pix] = make_float4(pass.x, pass.y, pass.z, 0.0f);
+        if (GEN && accum) {
+            const float4 cum4 = accum[pix];
+            const V3 cum = accumulate(mk3(cum4.x, cum4.y, cum4.z), pass, f.iter0);
+            accum[pix] = make_float4(cum.x, cum.y, cum.z, f.iter0);
+        } else pass_buf[(size_t)it * pass_stride + pix] = make_float4(pass.x, pass.y, pass.z, 0.0f);
         }
     }
     rays = wave_sum(rays);
@@ -915,7 +921,7 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
             const dim3 tgrid((cap + 255) / 256);
             const int variant = (pcg ? 8 : 0) | (wide ? 4 : 0) | (spill ? 2 : 0) | (sc.ext ? 1 : 0);
             if (gen_in_tail) switch (variant) {
-#define CRT_TAIL_CASE(V, R, W, S, A) case V: hipLaunchKernelGGL((k_wf_tail<R, W, S, A, true>), tgrid, block, 0, stream, sc, f, q, b, dead, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats); break;
+#define CRT_TAIL_CASE(V, R, W, S, A) case V: hipLaunchKernelGGL((k_wf_tail<R, W, S, A, true>), tgrid, block, 0, stream, sc, f, q, b, dead, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, n_batch == 1 ? acc : (float4 *)nullptr, stats); break;
                 CRT_TAIL_CASE(2, 0, false, true, false)  CRT_TAIL_CASE(3, 0, false, true, true)
                 CRT_TAIL_CASE(4, 0, true, false, false)  CRT_TAIL_CASE(6, 0, true, true, false)  CRT_TAIL_CASE(7, 0, true, true, true)
                 CRT_TAIL_CASE(10, 1, false, true, false)  CRT_TAIL_CASE(11, 1, false, true, true)
@@ -924,7 +930,7 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
                 default: break;
             }
             else switch (variant) {
-#define CRT_TAIL_CASE(V, R, W, S, A) case V: hipLaunchKernelGGL((k_wf_tail<R, W, S, A>), tgrid, block, 0, stream, sc, f, q, b, b == 0 ? dead : 0ull, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats); break;
+#define CRT_TAIL_CASE(V, R, W, S, A) case V: hipLaunchKernelGGL((k_wf_tail<R, W, S, A>), tgrid, block, 0, stream, sc, f, q, b, b == 0 ? dead : 0ull, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, (float4 *)nullptr, stats); break;
                 CRT_TAIL_CASE(2, 0, false, true, false)  CRT_TAIL_CASE(3, 0, false, true, true)
                 CRT_TAIL_CASE(4, 0, true, false, false)  CRT_TAIL_CASE(6, 0, true, true, false)  CRT_TAIL_CASE(7, 0, true, true, true)
                 CRT_TAIL_CASE(10, 1, false, true, false)  CRT_TAIL_CASE(11, 1, false, true, true)
@@ -961,7 +967,8 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
         else hipLaunchKernelGGL((k_wf_shade<0, false>), sgrid, block, 0, stream, sc, f, q, b, (float4 *)wf.pass.ptr, accum_pixels, hit_ids);
         if (wf.time_kernels) { HIP_TRY(hipEventRecord(wf.ev[wf.ev_used + 2], stream)); wf.ev_used += 3; }
     }
-    hipLaunchKernelGGL(k_wf_accumulate, acc_grid, block, 0, stream, f, acc, (const float4 *)wf.pass.ptr, accum_pixels);
+    if (!(gen_in_tail && n_batch == 1))      // (the path kernel has accumulated its single iteration itself)
+        hipLaunchKernelGGL(k_wf_accumulate, acc_grid, block, 0, stream, f, acc, (const float4 *)wf.pass.ptr, accum_pixels);
     HIP_TRY(hipGetLastError());
     return true;
 }
