@@ -21,6 +21,7 @@ FLAG_FULL_IMAGE = 1
 FLAG_DEBUG_SMALL_STACK = 2
 FLAG_PER_BOUNCE_KERNELS = 4
 FLAG_PATH_KERNEL = 8
+FLAG_PATH_KERNEL_PERSISTENT = 16
 BVH_LBVH, BVH_SAH_REFINE, BVH_LEAF_COLLAPSE, BVH_WIDE, BVH_WIDE_DIRECT = 0, 1, 2, 4, 8
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT = 1, 2, 4, 8     # crt_material.type (rt_material.h:9-14)
 EXT_TEXTURE_INDEX, EXT_ALPHA_TEST = 1, 2     # crt_extensions_set (build extensions, off by default)

@@ -99,6 +99,7 @@ struct WavefrontState {
     uint32_t capacity = 0;           // paths the queues can hold
     DeviceBuffer ray_o[2], ray_d[2], thr[2], hit, counters, pass, query_rays;
     bool time_kernels = false;
+    bool tail_persist = false;       // the path kernel in its persistent form (k_wf_path) where it applies
     int tail_bounce = -1;            // >= 0: this dispatch ends in k_wf_tail from that bounce on (set per dispatch by the context, trace.hip)
     std::vector<hipEvent_t> ev;      // per bounce: before k_wf_extend, between it and k_wf_shade, after k_wf_shade
     size_t ev_used = 0;

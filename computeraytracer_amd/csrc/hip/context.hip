@@ -19,7 +19,7 @@ struct crt_context {
     hipStream_t stream = nullptr;
     // Two timing slots, like the reference's two frame slots with a fence each (vk_engine.h:18, vk_engine.cpp:1377):
     // dispatch i records into slot i % 2 and only waits if the dispatch two calls back has not finished yet.
-    struct TimingSlot { hipEvent_t start = nullptr, stop = nullptr; bool pending = false; int tune_mode = -1; float tune_scale = 1.0f; } slot[2];
+    struct TimingSlot { hipEvent_t start = nullptr, stop = nullptr; bool pending = false; int tune_mode = -1, tune_modes = 2; float tune_scale = 1.0f; } slot[2];
     // Small batches (up to kTailPaths paths: one sample of a 1080p frame) can finish in k_wf_tail, one lane per path through all
     // its bounces, instead of a k_wf_extend / k_wf_shade pair per bounce.  Which is faster depends on the scene: per-bounce
     // launches wait for the longest RAY of every bounce, the tail kernel for the longest PATH, which wins where some rays
@@ -27,7 +27,9 @@ struct crt_context {
     // are short (cirno 1080p: 1.6 instead of 1.0 ms).  Same image either way, so the context measures: the first
     // dispatches alternate, two by two, and after three timed samples of each the faster mode stays until the scene or
     // the configuration changes.  CRT_WF_TAIL_BOUNCE=n fixes the mode (n < 0: never, else the first bounce of the tail kernel).
-    struct TailTune { int decided = -2; uint32_t calls = 0, samples[2] = {0, 0}; float best[2] = {3.4e38f, 3.4e38f}; } tune;
+    // Modes: 0 = a kernel pair per bounce, 1 = one lane per path (k_wf_tail), 2 = the persistent path kernel (k_wf_path; only
+    // over an 8-wide tree with no extension set).
+    struct TailTune { int decided = -1; uint32_t calls = 0, samples[3] = {0, 0, 0}; float best[3] = {3.4e38f, 3.4e38f, 3.4e38f}; } tune;
     uint32_t slot_next = 0;
     hipEvent_t ev_build[2] = {nullptr, nullptr};
     std::string error;
@@ -151,11 +153,14 @@ int harvest_slot(crt_context *ctx, crt_context::TimingSlot &sl, bool block) {
     CTX_HIP(hipEventElapsedTime(&ms, sl.start, sl.stop));
     ctx->last_render_ms = ms;
     sl.pending = false;
-    if (sl.tune_mode >= 0 && ctx->tune.decided == -2) {
+    if (sl.tune_mode >= 0 && ctx->tune.decided < 0) {
         crt_context::TailTune &t = ctx->tune;
         t.best[sl.tune_mode] = std::min(t.best[sl.tune_mode], ms / sl.tune_scale);
         t.samples[sl.tune_mode]++;
-        if (t.samples[0] >= 3 && t.samples[1] >= 3) t.decided = t.best[1] < t.best[0] ? 0 : -1;
+        const int n_modes = sl.tune_modes;
+        bool done = true;
+        for (int m = 0; m < n_modes; m++) done = done && t.samples[m] >= 3;
+        if (done) { int b = 0; for (int m = 1; m < n_modes; m++) if (t.best[m] < t.best[b]) b = m; t.decided = b; }
     }
     sl.tune_mode = -1;
     return CRT_OK;
@@ -205,18 +210,22 @@ int begin_timing(crt_context *ctx, crt_context::TimingSlot **out) {
 void pick_tail(crt_context *ctx, crt_context::TimingSlot *sl, double paths, uint32_t iters) {
     static const int env_bounce = [] { const char *e = getenv("CRT_WF_TAIL_BOUNCE"); return e ? atoi(e) : -100; }();      // unset: measure
     static const double max_paths = [] { const char *e = getenv("CRT_WF_TAIL_PATHS"); return e ? atof(e) : 4.2e6; }();
-    ctx->wf.tail_bounce = -1;
+    static const bool env_persist = [] { const char *e = getenv("CRT_WF_PATH_PERSIST"); return e && atoi(e) != 0; }();
+    ctx->wf.tail_bounce = -1; ctx->wf.tail_persist = false;
     sl->tune_mode = -1;
     if (ctx->cfg.tracer != CRT_TRACER_WAVEFRONT || ctx->instrumented || ctx->wf.time_kernels || paths > max_paths || iters == 0) return;
+    auto set_mode = [&](int mode) { ctx->wf.tail_bounce = mode ? 0 : -1; ctx->wf.tail_persist = mode == 2; };
+    const int n_modes = (ctx->build.n_wide != 0 && ctx->ext == 0) ? 3 : 2;
     if (ctx->cfg.flags & CRT_FLAG_PER_BOUNCE_KERNELS) return;
-    if (ctx->cfg.flags & CRT_FLAG_PATH_KERNEL) { ctx->wf.tail_bounce = 0; return; }
-    if (env_bounce != -100) { ctx->wf.tail_bounce = env_bounce < 0 ? -1 : env_bounce; return; }
+    if (ctx->cfg.flags & CRT_FLAG_PATH_KERNEL) { set_mode(1); return; }
+    if (ctx->cfg.flags & CRT_FLAG_PATH_KERNEL_PERSISTENT) { set_mode(n_modes == 3 ? 2 : 1); return; }
+    if (env_bounce != -100) { ctx->wf.tail_bounce = env_bounce < 0 ? -1 : env_bounce; ctx->wf.tail_persist = env_persist; return; }
     crt_context::TailTune &t = ctx->tune;
-    if (t.decided != -2) { ctx->wf.tail_bounce = t.decided; return; }
-    const int mode = (int)((t.calls / 2u) & 1u);
+    if (t.decided >= 0) { set_mode(t.decided < n_modes ? t.decided : 1); return; }
+    const int mode = (int)((t.calls / 2u) % (uint32_t)n_modes);
     t.calls++;
-    ctx->wf.tail_bounce = mode ? 0 : -1;
-    sl->tune_mode = mode; sl->tune_scale = (float)iters;
+    set_mode(mode);
+    sl->tune_mode = mode; sl->tune_modes = n_modes; sl->tune_scale = (float)iters;
 }
 
 // n_batch > 1 (wavefront tracer only): p.camera.iteration is the first iteration of the batch, seeds[b] its b-th seed.

@@ -786,6 +786,141 @@ __global__ __launch_bounds__(256) void k_wf_tail(DeviceScene sc, Frame f, WfQueu
     if ((threadIdx.x & 63u) == 0u && rays) atomicAdd(&stats->rays, rays);
 }
 
+// The path kernel with persistent waves: a lane whose path ended takes the next entry of the wave's pool as soon as
+// `refill` lanes are idle (k_wf_extend's work fetch), lanes whose ray is done wait for a shade phase (`shade_lanes` of
+// them, or nobody left to step), everybody else takes one traversal step per iteration.
+// Faster than one lane per path where traversal is compute-bound (cirno 1080p: 1.56 instead of 1.84 ms per unbatched
+// sample), slower where it waits for memory (config 5: 3.17 instead of 2.87 ms per frame): the context measures.
+// GEN / accum as in k_wf_tail.
+template <int RNGM, bool WIDE, bool SPILL, bool EXT, bool GEN>
+__global__ __launch_bounds__(256) void k_wf_path(DeviceScene sc, Frame f, WfQueues q, uint32_t bounce0, unsigned long long dead, uint32_t shade_lanes,
+                                                 float4 *pass_buf, uint32_t pass_stride, uint32_t *hit_ids, float4 *accum, DeviceStats *stats) {
+    __shared__ uint2 s_stack[kWideLds * 256];
+    __shared__ uint8_t s_order[WIDE ? kWideOrderBytes : 4];
+    if (WIDE) { wide_order_table(s_order, threadIdx.x, blockDim.x); __syncthreads(); }
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t *counts = q.counts + bounce0 * kShards * kCtrStride;
+    uint32_t *cursors = q.cursors + bounce0 * kShards * kCtrStride;
+    if (bounce0 == 0 && blockIdx.x == 0) {
+        unsigned long long n = wave_sum(threadIdx.x < kShards ? (unsigned long long)counts[threadIdx.x * kCtrStride] : 0ull);
+        if (lane == 0) atomicAdd(&stats->rays, n - (wave == 0 ? dead : 0ull));
+    }
+    const uint32_t in = bounce0 & 1;
+    const uint32_t ns = q.n_shards, per = ns >= 8 ? ns / 8 : 1;
+    const uint32_t home = home_shard(blockIdx.x, wave, ns);
+    uint32_t k = 0, pool_next = 0, pool_end = 0, pool_base = 0, pool_shard = 0;
+    bool drained = false;
+    bool busy = false, shading = false;      // per lane: has a path; its ray is traced and waits for the shade phase
+    using LT = LaneTrav<WIDE, SPILL>;
+    LT lt;
+    typename LT::Entry spill[LT::kSpill];
+    typename LT::Entry *stack = (typename LT::Entry *)s_stack + threadIdx.x;
+    const int lds_depth = (int)q.lds_depth;
+    V3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), color = mk3(0, 0, 0);
+    lt.begin(o, d);
+    uint32_t pix = 0, it = 0, b = 0;
+    Rng<RNGM> rng;
+    rng.unpack(0, 1);
+    unsigned long long rays = 0;
+    for (;;) {
+        const unsigned long long idle = __ballot(!busy);
+        if (!drained && (uint32_t)__popcll(idle) >= q.refill) {
+            if (pool_next >= pool_end) {
+                while (k < ns) {
+                    const uint32_t s = ns >= 8 ? (home + 8 * (k % per) + (k / per)) % ns : (home + k) % ns;
+                    const uint32_t n = counts[s * kCtrStride];
+                    uint32_t base = n;
+                    if (n != 0) {
+                        uint32_t *cursor = cursors + s * kCtrStride;
+                        if (lane == 0 && *(volatile uint32_t *)cursor < n) base = atomicAdd(cursor, 64u);
+                        base = __shfl(base, 0);
+                        if (base < n) { pool_base = s * q.shard_cap; pool_shard = s; pool_next = base; pool_end = min(n, base + 64u); break; }
+                    }
+                    k++;
+                    {
+                        const uint32_t kk = k + lane;
+                        const uint32_t sl = ns >= 8 ? (home + 8 * (kk % per) + (kk / per)) % ns : (home + kk) % ns;
+                        const bool live = kk < ns && *(volatile uint32_t *)(cursors + sl * kCtrStride) < counts[sl * kCtrStride];
+                        const unsigned long long m = __ballot(live);
+                        k = m ? k + (uint32_t)__builtin_ctzll(m) : ns;
+                    }
+                }
+                if (k >= ns) drained = true;
+            }
+            if (!drained) {
+                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t i = pool_next + rank;
+                if (!busy && i < pool_end) {
+                    bool live;
+                    if constexpr (GEN) {      // queue slot -> virtual tile -> pixel -> camera ray (k_wf_generate's code)
+                        const uint32_t vt = pool_shard * q.tiles_per_shard + (i >> 6);
+                        it = vt / f.n_tiles;
+                        uint32_t x = 0, y = 0, prow = 0;
+                        live = vt < f.n_tiles * f.n_batch && tile_pixel(f, vt - it * f.n_tiles, i & 63u, x, y, prow);
+                        rng.init(f.seeds[it < kBatchMax ? it : 0], x, y, y * f.width + x, f.iter0 + (float)it);
+                        float ox, oy; hash_2(rng, ox, oy);
+                        const float u = ((float)x + ox) / (float)f.width, v = ((float)y + oy) / (float)f.height;
+                        camera_get_ray(f.p.camera, u, v, rng, o, d);
+                        color = mk3(1.0f, 1.0f, 1.0f);
+                        pix = prow * f.width + x;
+                    } else {
+                        const uint32_t slot = pool_base + i;
+                        const float4 o4 = q.ray_o[in][slot], d4 = q.ray_d[in][slot];
+                        live = f2u(d4.w) != kDeadPixel;
+                        float4 c4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+                        if (RNGM != 0 || bounce0 != 0) c4 = q.thr[in][slot];
+                        o = mk3(o4.x, o4.y, o4.z); d = mk3(d4.x, d4.y, d4.z); color = mk3(c4.x, c4.y, c4.z);
+                        pix = f2u(d4.w); it = 0;
+                        if (f.n_batch > 1) { it = pix >> kPixBits; pix &= (1u << kPixBits) - 1u; }
+                        rng.unpack((uint64_t)f2u(o4.w) | ((uint64_t)f2u(c4.w) << 32), ((uint64_t)(uint32_t)(f.iter0 + (float)it) << 1) | 1u);
+                    }
+                    if (live) {
+                        b = bounce0;
+                        lt.begin(o, d);
+                        busy = true; shading = sc.n_pairs == 0;
+                    }
+                }
+                pool_next = min(pool_end, pool_next + (uint32_t)__popcll(idle));
+            }
+        }
+        if (__ballot(busy) == 0) {
+            if (drained) break;
+            continue;
+        }
+        const bool stepping = busy && !shading;
+        const uint32_t n_wait = (uint32_t)__popcll(__ballot(busy && shading));
+        if (n_wait >= shade_lanes || __ballot(stepping) == 0) {
+            if (busy && shading) {
+                if (b != 0) rays++;
+                const uint32_t id = lt.tr.best_id;
+                if (b == 0 && it + 1 == f.n_batch) hit_ids[pix] = id;
+                V3 emitted = mk3(0.0f, 0.0f, 0.0f), pass = mk3(0.0f, 0.0f, 0.0f);
+                bool alive = false;
+                if (id == kIdMiss) pass = shade_miss(f.p, d, color);
+                else alive = shade_hit<RNGM, EXT>(sc, o, d, lt.tr.best_t, id, rng, color, emitted, pass);
+                if (alive && b + 1 >= f.max_bounces) { alive = false; pass = mk3(0.0f, 0.0f, 0.0f); }
+                if (alive) { b++; lt.begin(o, d); shading = sc.n_pairs == 0; }
+                else {
+                    pass = pass * (1.0f / 1.0f);
+                    if (GEN && accum) {
+                        const float4 cum4 = accum[pix];
+                        const V3 cum = accumulate(mk3(cum4.x, cum4.y, cum4.z), pass, f.iter0);
+                        accum[pix] = make_float4(cum.x, cum.y, cum.z, f.iter0);
+                    } else pass_buf[(size_t)it * pass_stride + pix] = make_float4(pass.x, pass.y, pass.z, 0.0f);
+                    busy = false; shading = false;
+                }
+            }
+        } else if (stepping) {
+            Counts cnt = {0, 0};
+            const bool more = lt.at_leaf() ? lt.template leaf<false, EXT>(sc, s_order, stack, spill, lds_depth, cnt)
+                                           : lt.template inner<false>(sc, s_order, stack, spill, lds_depth, cnt);
+            if (!more) shading = true;
+        }
+    }
+    rays = wave_sum(rays);
+    if (lane == 0 && rays) atomicAdd(&stats->rays, rays);
+}
+
 // main()'s accumulation (compute.comp:470-476) for the iterations of a batch, in iteration order: every active pixel
 // owns exactly one path per iteration and k_wf_shade stored that path's radiance when it ended.
 __global__ __launch_bounds__(256) void k_wf_accumulate(Frame f, float4 *accum, const float4 *pass_buf, uint32_t pass_stride) {
@@ -908,6 +1043,8 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
     static const uint32_t env_packet_visits = [] { const char *e = getenv("CRT_WF_PACKET_VISITS"); return (uint32_t)(e ? atoi(e) : 32); }();
     const bool packets = env_primary && sc.wide && !sc.ext && !fs.instrumented && sch.wide_levels <= kWideSpill && wf.tail_bounce != 0;
     const bool first_bounce = packets && env_first && params.camera.shouldRenderAABB == 0u;
+    static const uint32_t env_path_shade = [] { const char *e = getenv("CRT_WF_PATH_SHADE_LANES"); int v = e ? atoi(e) : 16; return (uint32_t)(v < 1 ? 1 : v > 64 ? 64 : v); }();
+    const bool persist = wf.tail_persist && sc.wide && !sc.ext;      // k_wf_path instead of k_wf_tail (8-wide tree, no extension)
     const bool gen_in_tail = wf.tail_bounce == 0 && env_first && params.camera.shouldRenderAABB == 0u;      // the path kernel makes its own camera rays
     if (!first_bounce && !gen_in_tail) {
         if (pcg) hipLaunchKernelGGL((k_wf_generate<1>), gen_grid, block, 0, stream, sc, f, q, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, stats);
@@ -920,6 +1057,16 @@ bool launch_wavefront(hipStream_t stream, const DeviceSceneHost &sch, const Fram
             const bool wide = sc.wide != nullptr, spill = sc.ext != 0 || !(wide && sch.wide_levels <= q.lds_depth + 1u);
             const dim3 tgrid((cap + 255) / 256);
             const int variant = (pcg ? 8 : 0) | (wide ? 4 : 0) | (spill ? 2 : 0) | (sc.ext ? 1 : 0);
+            if (persist) {
+                float4 *direct = gen_in_tail && n_batch == 1 ? acc : (float4 *)nullptr;
+                const unsigned long long dead_t = b == 0 ? dead : 0ull;
+                const int pv = (pcg ? 2 : 0) | (spill ? 1 : 0);
+#define CRT_PATH_CASE(V, R, S) case V: if (gen_in_tail) hipLaunchKernelGGL((k_wf_path<R, true, S, false, true>), pgrid, block, 0, stream, sc, f, q, b, dead_t, env_path_shade, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, direct, stats); \
+                                       else hipLaunchKernelGGL((k_wf_path<R, true, S, false, false>), pgrid, block, 0, stream, sc, f, q, b, dead_t, env_path_shade, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, direct, stats); break;
+                switch (pv) { CRT_PATH_CASE(0, 0, false) CRT_PATH_CASE(1, 0, true) CRT_PATH_CASE(2, 1, false) CRT_PATH_CASE(3, 1, true) default: break; }
+#undef CRT_PATH_CASE
+                break;
+            }
             if (gen_in_tail) switch (variant) {
 #define CRT_TAIL_CASE(V, R, W, S, A) case V: hipLaunchKernelGGL((k_wf_tail<R, W, S, A, true>), tgrid, block, 0, stream, sc, f, q, b, dead, (float4 *)wf.pass.ptr, accum_pixels, hit_ids, n_batch == 1 ? acc : (float4 *)nullptr, stats); break;
                 CRT_TAIL_CASE(2, 0, false, true, false)  CRT_TAIL_CASE(3, 0, false, true, true)

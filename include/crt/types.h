@@ -168,10 +168,12 @@ enum {
                                       LDS stack) runs on every scene */
     /* Small wavefront batches (up to 4.2 M paths: one sample of a 1080p frame) can run as a k_wf_extend / k_wf_shade pair
      * per bounce or, each path through all its bounces in one lane, in k_wf_tail.  The image is the same bit for bit;
-     * which is faster depends on the scene, so by default the context times both over its first dispatches and keeps
-     * the faster (context.hip, TailTune).  These two flags fix the choice. */
+     * which is faster depends on the scene, so by default the context times the forms over its first dispatches and keeps
+     * the fastest (context.hip, TailTune).  These flags fix the choice. */
     CRT_FLAG_PER_BOUNCE_KERNELS = 1u << 2,
-    CRT_FLAG_PATH_KERNEL = 1u << 3
+    CRT_FLAG_PATH_KERNEL = 1u << 3,           /* one lane per path, a thread per pixel (k_wf_tail) */
+    CRT_FLAG_PATH_KERNEL_PERSISTENT = 1u << 4 /* persistent waves that refill idle lanes (k_wf_path; 8-wide tree without extensions,
+                                                 else as CRT_FLAG_PATH_KERNEL) */
 };
 
 /* crt_extensions_set: build extensions with no counterpart in the reference, all off by default.

@@ -167,7 +167,7 @@ def test_direct_mode_errors(ctx):
 
 
 # ---- small batches: a kernel pair per bounce or one lane per path (k_wf_tail); CRT_FLAG_PER_BOUNCE_KERNELS / CRT_FLAG_PATH_KERNEL ----
-MODES = [abi.FLAG_PER_BOUNCE_KERNELS, abi.FLAG_PATH_KERNEL]
+MODES = [abi.FLAG_PER_BOUNCE_KERNELS, abi.FLAG_PATH_KERNEL, abi.FLAG_PATH_KERNEL_PERSISTENT]
 
 
 @pytest.mark.parametrize("name,w,h,n_iter,bvh,rng", [("book1", 200, 112, 3, abi.BVH_SAH_REFINE | abi.BVH_WIDE, abi.RNG_REF),
@@ -190,7 +190,7 @@ def test_path_kernel_and_per_bounce_kernels_match_the_oracle(golden_dir, name, w
             rays.append(c.stats().rays)
         finally:
             c.close()
-    assert rays[0] == rays[1] == ref[2].rays          # both count hit_world calls
+    assert rays[0] == rays[1] == rays[2] == ref[2].rays          # all count hit_world calls
 
 
 def test_path_kernel_debug_view_and_extensions(golden_dir):
