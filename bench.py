@@ -54,32 +54,108 @@ def requested_gpus(argv):
     return n
 
 
+PHASES = ("start", "dist_init", "scene_upload", "bvh_build", "instrumented_step", "warmup", "timed_steps", "reduce",
+          "comm_init", "first_gather", "timed_gather", "gather_check", "report", "done")
+
+
+class Phase:
+    """Where this rank is, for the day a multi-GPU run hangs: kept in memory for the rank's own watchdog and, when the
+    self-launcher started the rank, in a one-line file the launcher reads (CRT_BENCH_PHASE_DIR/rank_<r>)."""
+    def __init__(self, rank):
+        self.rank, self.name, self.t0 = rank, "start", time.time()
+        d = os.environ.get("CRT_BENCH_PHASE_DIR", "")
+        self.path = os.path.join(d, f"rank_{rank}") if d else None
+        self.set("start")
+
+    def set(self, name):
+        assert name in PHASES, name
+        self.name = name
+        if self.path:
+            try:
+                with open(self.path, "w") as f:
+                    f.write(name)
+            except OSError:
+                pass
+
+
+def start_watchdog(phase, world, seconds):
+    """A rank of a multi-GPU run that is not done after `seconds` (stuck in ncclCommInitRank, a collective, a kernel)
+    prints ONE JSON line saying which rank and which phase, and ends the process with exit code 3: the driver's limit
+    would otherwise kill the run with nothing on stdout.  Daemon thread; os._exit because the main thread may be inside
+    a collective that never returns."""
+    import threading
+
+    def watch():
+        while time.time() - phase.t0 < seconds:
+            if phase.name == "done":
+                return
+            time.sleep(0.25)
+        if phase.name == "done":
+            return
+        print(json.dumps({"error": "timeout", "rank": phase.rank, "n_gpus": world, "phase": phase.name,
+                          "after_s": round(time.time() - phase.t0, 1)}), flush=True)
+        os._exit(3)
+
+    t = threading.Thread(target=watch, daemon=True)
+    t.start()
+    return t
+
+
+def rank_timeout_s():
+    return float(os.environ.get("CRT_BENCH_RANK_TIMEOUT", "420"))      # below the launcher's limit, which is below the driver's (600 s in round 2)
+
+
 def launch_ranks(argv, n_gpus):
     """Parent of a self-launched multi-GPU run.  It never touches the GPU (no torch, no libcrt.so: nothing has been
-    imported yet), starts the ranks as child processes, waits, and fails if any of them did.  Rank 0 prints the JSON line."""
+    imported yet), starts the ranks as child processes, waits, and fails if any of them did.  Rank 0 prints the JSON line;
+    when a rank fails or the run times out the parent prints a JSON line with "error", the rank and the phase it was in."""
     import socket
     import subprocess
+    import tempfile
+    # a listening socket keeps the port reserved until just before the ranks start (bind-close-reuse would let another
+    # process take it in between: ADVICE r2); SO_REUSEADDR lets rank 0's store bind it right after the close
     s = socket.socket()
+    s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
+    phase_dir = tempfile.mkdtemp(prefix="crt_bench_phase_")
+    plan = launcher_plan(argv, n_gpus, port, base_env=dict(os.environ, CRT_BENCH_PHASE_DIR=phase_dir))
     s.close()
-    procs = [subprocess.Popen(a, env=e) for a, e in launcher_plan(argv, n_gpus, port)]
-    deadline = time.time() + float(os.environ.get("CRT_BENCH_LAUNCH_TIMEOUT", "1500"))
+    procs = [subprocess.Popen(a, env=e) for a, e in plan]
+    deadline = time.time() + float(os.environ.get("CRT_BENCH_LAUNCH_TIMEOUT", "480"))
     codes = [None] * n_gpus
+    timed_out = False
     while any(c is None for c in codes):
         for i, p in enumerate(procs):
             if codes[i] is None:
                 codes[i] = p.poll()
         failed = [c for c in codes if c not in (None, 0)]
-        if failed or time.time() > deadline:      # one rank died (or the run hangs): the others would wait in a collective forever
+        timed_out = time.time() > deadline
+        if failed or timed_out:      # one rank died (or the run hangs): the others would wait in a collective forever
             for i, p in enumerate(procs):
                 if codes[i] is None:
                     p.kill()                        # exactly the PIDs started above
-                    codes[i] = p.wait()
+                    p.wait()
+                    codes[i] = "killed"
             break
         time.sleep(0.05)
+
+    def phase_of(r):
+        try:
+            with open(os.path.join(phase_dir, f"rank_{r}")) as f:
+                return f.read().strip() or "unknown"
+        except OSError:
+            return "not started"
+
     bad = [(i, c) for i, c in enumerate(codes) if c != 0]
+    phases = {r: phase_of(r) for r in range(n_gpus)}
+    import shutil
+    shutil.rmtree(phase_dir, ignore_errors=True)
     if bad:
+        own = [(i, c) for i, c in bad if c != "killed"]      # ranks that ended by themselves; the rest were ended by this launcher
+        print(json.dumps({"error": "timeout" if timed_out and not own else "rank_failed", "n_gpus": n_gpus,
+                          "failed_ranks": [{"rank": i, "exit": c, "phase": phases[i]} for i, c in (own or bad)],
+                          "phases": {str(r): ph for r, ph in phases.items()}}), flush=True)
         print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
         return 1
     return 0
@@ -237,6 +313,9 @@ def main():
                          f"or under torch.distributed.run with --nproc-per-node {args.gpus}")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    phase = Phase(rank)
+    if world > 1:
+        start_watchdog(phase, world, rank_timeout_s())
     # CRT_BENCH_REHEARSE=1: every rank on GPU 0 and gloo instead of RCCL, to rehearse the multi-rank path of this script
     # on a one-GPU box (RCCL refuses two ranks on one device); never set by the driver
     rehearse = os.environ.get("CRT_BENCH_REHEARSE", "") == "1"
@@ -247,6 +326,7 @@ def main():
     if world > 1 or os.environ.get("CRT_BENCH_FORCE_DIST", "") == "1":
         import torch
         import torch.distributed as dist
+        phase.set("dist_init")
         torch.cuda.set_device(local_rank)
         if rehearse:
             dist.init_process_group("gloo")
@@ -265,12 +345,14 @@ def main():
     if not args.bvh:
         args.bvh = "direct" if rebuild else "sah-wide"
 
+    phase.set("scene_upload")
     ctx = abi.Context(local_rank)
     ctx.configure(W, H, tracer=tracer, band_rank=rank, band_world=world)
     ctx.upload(scene)
     bvh_flags = {"lbvh": abi.BVH_LBVH, "sah": abi.BVH_SAH_REFINE, "collapse": abi.BVH_LEAF_COLLAPSE,
                  "lbvh-wide": abi.BVH_LBVH | abi.BVH_WIDE, "sah-wide": abi.BVH_SAH_REFINE | abi.BVH_WIDE, "direct": abi.BVH_WIDE_DIRECT}[args.bvh]
     wide = args.bvh.endswith("-wide") and tracer == abi.TRACER_WAVEFRONT
+    phase.set("bvh_build")
     build_ms = ctx.build(bvh_flags)
     build_ms = ctx.build(bvh_flags)   # second build: allocations are warm, this is the device time of the build alone
     spp = 1 if rebuild else max(1, args.spp_per_step)
@@ -288,6 +370,7 @@ def main():
             ctx.render(scene.params, 1, seeds[first_iter - 1 + i:first_iter + i])
 
     # V, T, D for the bytes-per-ray model: one instrumented dispatch (untimed)
+    phase.set("instrumented_step")
     ctx.stats_reset()
     ctx.set_instrumented(True)
     run(1, 1)
@@ -298,13 +381,17 @@ def main():
     T = st.prim_tests / max(st.rays, 1)
     D = st.rays / max(st.paths, 1)
 
+    phase.set("warmup")
     run(1, args.warmup)
     ctx.sync()
     ctx.stats_reset()
     # HIP events around every k_wf_extend launch, on the stream it is launched on.  Not for the per-frame rebuild workload:
     # per-kernel timing makes every dispatch wait for the previous one and keeps small batches on the per-bounce kernels
     # (crt_set_kernel_timing, abi.h), and that workload's figure is the frame time
-    ctx.set_kernel_timing(not rebuild)
+    # CRT_BENCH_NO_KERNEL_TIMING=1 (experiments only): whole-step time without the per-kernel events, which also lets the
+    # context's small-batch kernel choice (CRT_WF_TAIL_*) apply
+    kernel_timing = not rebuild and os.environ.get("CRT_BENCH_NO_KERNEL_TIMING", "") != "1"
+    ctx.set_kernel_timing(kernel_timing)
 
     def barrier():
         if dist is not None:
@@ -314,9 +401,11 @@ def main():
         ctx.sync()
 
     barrier()
+    phase.set("timed_steps")
     t0 = time.perf_counter()
     run(args.warmup + 1, args.steps)
     ctx.sync()
+    own_elapsed = time.perf_counter() - t0      # this rank's own steps, before it waits for the others: band imbalance shows here
     barrier()
     elapsed = time.perf_counter() - t0
     st = ctx.stats()
@@ -326,12 +415,21 @@ def main():
     gather_ms, gather_path, gather_check = None, None, None
     if dist is not None:
         import torch
+        phase.set("reduce")
         tdev = torch.device("cpu") if rehearse else torch.device("cuda", local_rank)
         t = torch.tensor([elapsed, rays], dtype=torch.float64, device=tdev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed, rays = float(tmax[0]), float(t[1])
+        # every rank's own time for its steps (before the closing barrier) and its ray count, gathered so the line can show
+        # the spread: rows of sky and rows of city cost differently, and the slowest rank sets `value`
+        per = torch.zeros(2 * world, dtype=torch.float64, device=tdev)
+        per[2 * rank], per[2 * rank + 1] = own_elapsed, float(st.rays)
+        dist.all_reduce(per, op=dist.ReduceOp.SUM)
+        per = per.cpu().numpy().reshape(world, 2)
+        rank_ms = [float(x) / args.steps * 1e3 for x in per[:, 0]]
+        per_rank_rays = [float(x) for x in per[:, 1]]
         # gather the finished image: ONE all-gather of the packed band buffers + un-interleave, outside `value`
         gather_path = "rccl-native"
         if rehearse:
@@ -349,13 +447,16 @@ def main():
         else:
             # the product path: crt_comm_init + crt_image_gather inside libcrt.so (csrc/dist/gather_rccl.hip); torch.distributed
             # only carries the 128-byte communicator id from rank 0 to the others
+            phase.set("comm_init")
             idt = torch.zeros(abi.COMM_ID_BYTES, dtype=torch.uint8, device=tdev)
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(abi.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, 0)
             ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+            phase.set("first_gather")
             ctx.image_gather(); ctx.sync()            # the first collective on a communicator sets its channels up: untimed
             torch.cuda.synchronize(); dist.barrier()
+            phase.set("timed_gather")
             g0 = time.perf_counter()
             ctx.image_gather(); ctx.sync()
             gather_ms = (time.perf_counter() - g0) * 1e3
@@ -363,6 +464,7 @@ def main():
             ctx.comm_destroy()
         # every rank's bands arrived: each pixel of the rendered grid carries the last iteration's number in .w, and
         # this rank's own rows are the ones it rendered
+        phase.set("gather_check")
         last_iter = float((args.warmup + args.steps) * spp) if not rebuild else 1.0
         own = abi.band_rows(H, rank, world)
         gh, gw = (H // 8) * 8, (W // 8) * 8
@@ -374,6 +476,7 @@ def main():
         dist.all_reduce(gt, op=dist.ReduceOp.MAX)
         gather_ms = float(gt[0])
 
+    phase.set("report")
     if rank == 0:
         mrays = rays / elapsed / 1e6
         # bytes/ray of the whole pipeline = 32 V + 48 T + 96 (48-byte queue entry written + read) + 32 / D (accumulation)
@@ -451,11 +554,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene)
             line["parity"] = parity_sample(scene, tracer, bvh_flags, local_rank)
+        if dist is not None:
+            # per-rank spread: ms per step of every rank's own steps, and its share of the rays
+            line["config"]["rank_ms_per_step"] = {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4),
+                                                  "all": [round(x, 4) for x in rank_ms]}
+            line["config"]["rank_rays_share"] = {"min": round(min(per_rank_rays) / max(sum(per_rank_rays), 1.0), 5),
+                                                 "max": round(max(per_rank_rays) / max(sum(per_rank_rays), 1.0), 5)}
         print(json.dumps(line), flush=True)
     ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    phase.set("done")
 
 
 if __name__ == "__main__":

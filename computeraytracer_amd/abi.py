@@ -187,7 +187,7 @@ def comm_unique_id():
     buf = (C.c_uint8 * COMM_ID_BYTES)()
     rc = lib.crt_comm_unique_id(buf)
     if rc != 0:
-        raise CrtError(f"crt_comm_unique_id failed ({rc}): RCCL could not be loaded")
+        raise CrtError(f"crt_comm_unique_id failed ({rc}): {lib.crt_host_last_error().decode()}")
     return bytes(buf)
 
 

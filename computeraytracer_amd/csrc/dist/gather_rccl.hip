@@ -11,6 +11,8 @@
 
 #include <dlfcn.h>
 
+#include <cstdlib>
+
 #include <mutex>
 #include <string>
 
@@ -41,10 +43,20 @@ Rccl g_rccl;
 std::once_flag g_rccl_once;
 
 void load_rccl() {
-    const char *names[] = {"librccl.so.1", "librccl.so"};
-    for (const char *n : names) if (!g_rccl.handle) g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);     // a copy the process already holds
-    for (const char *n : names) if (!g_rccl.handle) g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (!g_rccl.handle) { g_rccl.error = std::string("RCCL is not loadable: ") + (dlerror() ? dlerror() : "dlopen failed"); return; }
+    // CRT_RCCL_SONAME: one soname or path to bind instead of the defaults (a site-specific RCCL build; the CPU suite uses it
+    // to check that a box without RCCL gets an error code and a message, not a crash)
+    const char *override_name = getenv("CRT_RCCL_SONAME");
+    const char *defaults[] = {"librccl.so.1", "librccl.so"};
+    const char *one[] = {override_name};
+    const char *const *names = override_name && *override_name ? one : defaults;
+    const int n_names = override_name && *override_name ? 1 : 2;
+    for (int i = 0; i < n_names; i++) if (!g_rccl.handle) g_rccl.handle = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);     // a copy the process already holds
+    for (int i = 0; i < n_names; i++) if (!g_rccl.handle) g_rccl.handle = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!g_rccl.handle) {
+        const char *e = dlerror();      // ONE call: dlerror() clears the message it returns
+        g_rccl.error = std::string("RCCL is not loadable: ") + (e ? e : "dlopen failed");
+        return;
+    }
     auto sym = [&](const char *s) { void *p = dlsym(g_rccl.handle, s); if (!p && g_rccl.error.empty()) g_rccl.error = std::string("RCCL lacks ") + s; return p; };
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");

@@ -12,6 +12,8 @@
 #include "gather_internal.h"
 #include "crt/abi.h"
 
+namespace crt { void set_host_error(const std::string &msg); }      // host/host.cpp: the thread-local message behind crt_host_last_error()
+
 using namespace crt;
 
 struct crt_context {
@@ -653,7 +655,9 @@ int crt_image_copy_to_device(crt_context *ctx, void *dst_device, size_t n_bytes)
 int crt_comm_unique_id(void *id) {
     if (!id) return CRT_ERR_INVALID;
     std::string err;
-    return comm_unique_id(id, err) ? CRT_OK : CRT_ERR_HIP;
+    if (comm_unique_id(id, err)) return CRT_OK;
+    set_host_error("crt_comm_unique_id: " + err);      // no context to hold the message: crt_host_last_error() (thread-local) has it
+    return CRT_ERR_HIP;
 }
 
 int crt_comm_init(crt_context *ctx, const void *id, uint32_t rank, uint32_t world) {

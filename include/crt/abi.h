@@ -160,6 +160,8 @@ int crt_image_copy_to_device(crt_context *ctx, void *dst_device, size_t n_bytes)
  * (dlopen of librccl.so.1), libcrt.so has no link-time dependency on it.
  *   crt_comm_unique_id   rank 0 makes the id (ncclGetUniqueId) and hands its CRT_COMM_ID_BYTES bytes to the other ranks
  *                        by whatever channel the engine has (a socket, MPI, a file; the bench uses torch.distributed);
+ *                        it has no context, so on failure the message is crt_host_last_error()'s (thread-local).
+ *                        CRT_RCCL_SONAME (environment) names the library to bind instead of librccl.so.1;
  *   crt_comm_init        collective over all ranks (ncclCommInitRank) on the context's GPU;
  *   crt_image_gather     enqueues the all-gather of the packed band buffers and the un-interleave on the context's
  *                        stream; full_dev = device buffer of width*height*4 floats that receives the whole frame on

@@ -40,10 +40,78 @@ def test_launcher_reports_a_failed_rank(tmp_path, monkeypatch):
     script = tmp_path / "fake_rank.py"
     script.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(3)\ntime.sleep(60)\n")
     real = b.launcher_plan
-    monkeypatch.setattr(b, "launcher_plan", lambda argv, n, port: [([sys.executable, str(script)], e) for _, e in real(argv, n, port)])
+    monkeypatch.setattr(b, "launcher_plan", lambda argv, n, port, base_env=None: [([sys.executable, str(script)], e) for _, e in real(argv, n, port, base_env)])
     import time
     t0 = time.time()
     assert b.launch_ranks(["--gpus", "3"], 3) == 1
     assert time.time() - t0 < 30
     script.write_text("import sys\nsys.exit(0)\n")
     assert b.launch_ranks(["--gpus", "2"], 2) == 0
+
+
+def _json_lines(text):
+    import json
+    out = []
+    for ln in text.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{"):
+            out.append(json.loads(ln))
+    return out
+
+
+def test_launcher_prints_a_diagnostic_line_for_a_failed_rank_and_for_a_hang(tmp_path, monkeypatch, capfd):
+    # a multi-GPU run that dies must leave ONE JSON line with "error", the rank and the phase it was in
+    b = _bench()
+    script = tmp_path / "fake_rank.py"
+    script.write_text(
+        "import os, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "sys.argv = ['bench.py']\n"
+        "import importlib.util\n"
+        "spec = importlib.util.spec_from_file_location('crt_bench', %r)\n"
+        "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+        "ph = m.Phase(int(os.environ['RANK']))\n"
+        "ph.set('comm_init')\n"
+        "if os.environ['RANK'] == '1' and os.environ.get('FAKE_FAIL') == '1':\n"
+        "    sys.exit(7)\n"
+        "time.sleep(60)\n" % (ROOT, os.path.join(ROOT, "bench.py")))
+    real = b.launcher_plan
+    monkeypatch.setattr(b, "launcher_plan", lambda argv, n, port, base_env=None: [([sys.executable, str(script)], e) for _, e in real(argv, n, port, base_env)])
+    # (a) rank 1 exits with 7 while in comm_init
+    monkeypatch.setenv("FAKE_FAIL", "1")
+    assert b.launch_ranks(["--gpus", "2"], 2) == 1
+    lines = _json_lines(capfd.readouterr().out)
+    assert len(lines) == 1 and lines[0]["error"] == "rank_failed" and lines[0]["n_gpus"] == 2
+    assert lines[0]["failed_ranks"] == [{"rank": 1, "exit": 7, "phase": "comm_init"}]
+    # (b) nobody fails, everybody hangs: the launcher's own limit ends the run and says where every rank was
+    monkeypatch.setenv("FAKE_FAIL", "0")
+    monkeypatch.setenv("CRT_BENCH_LAUNCH_TIMEOUT", "6")
+    assert b.launch_ranks(["--gpus", "2"], 2) == 1
+    lines = _json_lines(capfd.readouterr().out)
+    assert len(lines) == 1 and lines[0]["error"] == "timeout"
+    assert lines[0]["phases"] == {"0": "comm_init", "1": "comm_init"}
+
+
+def test_launch_timeout_defaults_sit_below_the_drivers_limit():
+    b = _bench()
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'CRT_BENCH_LAUNCH_TIMEOUT", "480"' in src          # the driver gave the bench 600 s in round 2
+    assert b.rank_timeout_s() <= 480.0
+
+
+def test_rank_watchdog_prints_rank_and_phase_then_exits(tmp_path):
+    # under torch.distributed.run there is no launcher of ours: every rank watches itself
+    import subprocess
+    code = (
+        "import os, sys, time\n"
+        "sys.argv = ['bench.py']\n"
+        "import importlib.util\n"
+        "spec = importlib.util.spec_from_file_location('crt_bench', %r)\n"
+        "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+        "ph = m.Phase(5); m.start_watchdog(ph, 8, 1.0); ph.set('first_gather')\n"
+        "time.sleep(30)\n" % os.path.join(ROOT, "bench.py"))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 3
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["error"] == "timeout" and lines[0]["rank"] == 5 and lines[0]["phase"] == "first_gather" and lines[0]["n_gpus"] == 8

@@ -1,4 +1,5 @@
-"""N > 1 path on CPU: 2 (and 3) gloo ranks exchange packed band buffers and must reassemble the exact image."""
+"""N > 1 path on CPU: 2, 3 and 8 gloo ranks exchange packed band buffers and must reassemble the exact image
+(8 ranks at the headline height 2160: ranks 0-5 own 34 bands, ranks 6-7 own 33, so the padded all-gather is exercised)."""
 import os
 import socket
 
@@ -23,6 +24,8 @@ def _worker(rank, world, port, h, w, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if world == 8 and h == 2160:
+        assert cdist.local_rows(h, rank, world) == (34 if rank < 6 else 33) * 8
     full = np.random.default_rng(7).random((h, w, 4)).astype(np.float32)        # the same "rendered frame" on every rank
     band = torch.from_numpy(cdist.pack_bands(full, rank, world))                  # what this rank's context would hold
     img = cdist.gather_image(band, h, world)
@@ -34,7 +37,7 @@ def _worker(rank, world, port, h, w, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,h,w", [(2, 64, 24), (2, 225, 40), (3, 100, 16)])
+@pytest.mark.parametrize("world,h,w", [(2, 64, 24), (2, 225, 40), (3, 100, 16), (8, 2160, 8)])
 def test_band_gather_reassembles_the_frame(world, h, w):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -43,7 +46,7 @@ def test_band_gather_reassembles_the_frame(world, h, w):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(240)
         assert p.exitcode == 0
     assert q.get(timeout=10) == 1.0
 

@@ -225,3 +225,58 @@ def test_asset_readers_reject_lying_headers_and_long_obj_lines(tmp_path):
     tris = abi.load_obj(str(obj))
     assert len(tris) == k - 2
     assert np.allclose(tris["v0"], [1, 0, 0]) and np.allclose(tris["v2"][-1], [np.cos(ang[-1]), np.sin(ang[-1]), 0], atol=1e-6)
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """ADVICE r2: load_rccl called dlerror() twice (the second call returns NULL) and built a std::string from it, so a box
+    without librccl segfaulted instead of reporting.  CRT_RCCL_SONAME points the loader at a library that does not exist;
+    a child process, because the loader runs once per process."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ['CRT_RCCL_SONAME'] = 'libcrt_no_such_rccl.so.9'\n"
+        "from computeraytracer_amd import abi\n"
+        "import ctypes as C\n"
+        "buf = (C.c_uint8 * abi.COMM_ID_BYTES)()\n"
+        "rc = abi.lib.crt_comm_unique_id(buf)\n"
+        "msg = abi.lib.crt_host_last_error().decode()\n"
+        "print(rc, '|', msg)\n"
+        "rc2 = abi.lib.crt_comm_unique_id(buf)\n"
+        "print(rc2)\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    first, second = r.stdout.strip().splitlines()
+    rc, msg = first.split(" | ", 1)
+    assert int(rc) == -2 and int(second) == -2
+    assert "RCCL is not loadable" in msg and "libcrt_no_such_rccl.so.9" in msg
+
+
+def test_lz4_decoder_against_real_liblz4_blocks():
+    """(f)2 pinned outside the repo: tests/golden/lz4_vectors.npz holds LZ4_compress_default outputs of the real liblz4
+    (tools/make_fixtures.py, which also asserts that LZ4_decompress_safe restores every crt_lz4_compress block).  The
+    in-tree decoder must restore every plaintext, at exact capacity, and refuse a capacity one byte short."""
+    v = np.load(os.path.join(ROOT, "tests", "golden", "lz4_vectors.npz"), allow_pickle=False)
+    plain, po, block, bo = v["plain"], v["plain_off"], v["block"], v["block_off"]
+    assert len(po) == len(bo) and len(po) - 1 >= 20
+    assert bytes(v["liblz4_version"]).decode().startswith("1.")
+    for i in range(len(po) - 1):
+        want = plain[po[i]:po[i + 1]]
+        blk = np.ascontiguousarray(block[bo[i]:bo[i + 1]])
+        out = np.full(len(want) + 8, 0xAB, np.uint8)
+        n = abi.lib.crt_lz4_decompress(blk.ctypes.data, len(blk), out.ctypes.data, len(want))
+        assert n == len(want), (i, n, len(want))
+        assert np.array_equal(out[:n], want) and (out[len(want):] == 0xAB).all(), i
+        if len(want) > 0:
+            assert abi.lib.crt_lz4_decompress(blk.ctypes.data, len(blk), out.ctypes.data, len(want) - 1) < 0, i
+        # the in-tree compressor's block for the same plaintext decodes to it as well (the real decoder's verdict on
+        # these blocks was taken when the vectors were made)
+        src = np.ascontiguousarray(want) if len(want) else np.zeros(1, np.uint8)
+        cap = abi.lib.crt_lz4_compress_bound(len(want))
+        mine = np.zeros(max(cap, 16), np.uint8)
+        k = abi.lib.crt_lz4_compress(src.ctypes.data, len(want), mine.ctypes.data, cap)
+        assert k > 0
+        back = np.zeros(max(len(want), 1), np.uint8)
+        assert abi.lib.crt_lz4_decompress(mine.ctypes.data, k, back.ctypes.data, len(want)) == len(want)
+        assert np.array_equal(back[:len(want)], want)

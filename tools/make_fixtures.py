@@ -6,6 +6,12 @@
   * earthmap.tx                          assets/earthmap.png (2048x1024) box-filtered to 512x256, TEXI container
   * oracle_vectors.npz                   outputs of the CPU oracle on fixed inputs (regression pins; the reference itself
                                          has no tests or golden data -- "parity unpinned")
+  * lz4_vectors.npz                      real LZ4 blocks: LZ4_compress_default outputs of the system liblz4 (1.9.3 in the build
+                                         container, /opt/conda/lib/liblz4.so.1) for ~20 buffers, with their plaintexts.  The
+                                         reference calls LZ4_compress_default / LZ4_decompress_safe (asset-lib/src/mesh_asset.cpp:51,106,
+                                         texture_asset.cpp:35,67); the in-tree codec has to decode what the real one writes, and the
+                                         real one has to decode what the in-tree one writes (asserted here, at generation time: the
+                                         library itself never travels to the GPU box, the vectors do)
 Nothing here copies reference source text; OBJ/PNG files are data and are stored re-encoded.
 """
 import ctypes as C
@@ -89,8 +95,69 @@ def oracle_vectors():
     print("oracle_vectors.npz", os.path.getsize(os.path.join(OUT, "oracle_vectors.npz")), "bytes")
 
 
+LZ4_SO = "/opt/conda/lib/liblz4.so.1"
+
+
+def lz4_vectors():
+    lz = C.CDLL(LZ4_SO)
+    lz.LZ4_versionString.restype = C.c_char_p
+    lz.LZ4_compressBound.argtypes = [C.c_int]
+    lz.LZ4_compress_default.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lz.LZ4_decompress_safe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    rng = np.random.default_rng(4242)
+    mesh = open(os.path.join(OUT, "monkey_smooth.mesh"), "rb").read()
+    hdr = np.frombuffer(mesh[:16], dtype=np.uint32)
+    blob = np.frombuffer(mesh[16 + int(hdr[2]):16 + int(hdr[2]) + int(hdr[3])], dtype=np.uint8)
+    # the monkey's vertex blob, decoded by the in-tree reader and cut to 40 KiB of PNCV floats
+    p, n, q, m = C.c_void_p(), C.c_uint32(), C.c_void_p(), C.c_uint32()
+    assert abi.lib.crt_mesh_file_read(os.path.join(OUT, "monkey_smooth.mesh").encode(), C.byref(p), C.byref(n), C.byref(q), C.byref(m)) == 0
+    verts = bytes((C.c_uint8 * (n.value * 44)).from_address(p.value))
+    abi.lib.crt_free(p); abi.lib.crt_free(q)
+    # ... and the real library agrees with the in-tree reader about that blob
+    back = np.zeros(n.value * 44 + m.value * 4, np.uint8)
+    got = lz.LZ4_decompress_safe(blob.ctypes.data, back.ctypes.data, len(blob), len(back))
+    assert got == len(back) and bytes(back[:n.value * 44]) == verts, "liblz4 and the in-tree reader disagree about monkey_smooth.mesh"
+    words = (b"the quick brown fox jumps over the lazy dog " * 40)
+    bufs = [
+        b"", b"\x00", b"a", b"ab" * 6, b"abcdefghijkl", b"abcdefghijklm", bytes(13), bytes(64), bytes(65536),
+        bytes(range(256)) * 8, words, words[:257], b"x" * 4096 + b"y",
+        rng.integers(0, 256, 1000, dtype=np.uint8).tobytes(), rng.integers(0, 256, 70000, dtype=np.uint8).tobytes(),
+        rng.integers(0, 4, 5000, dtype=np.uint8).tobytes(), rng.integers(0, 2, 70001, dtype=np.uint8).tobytes(),
+        np.arange(5000, dtype=np.uint32).tobytes(), verts[:40960], verts[40960:40960 + 12345],
+        np.tile(rng.integers(0, 256, 300, dtype=np.uint8), 300).tobytes(),          # matches at distance 300, long runs of them
+        (bytes(70000) + b"tail"),                                                  # a match longer than 65535
+    ]
+    plain, comp, p_off, c_off = [], [], [0], [0]
+    for b in bufs:
+        src = np.frombuffer(b, dtype=np.uint8).copy() if b else np.zeros(1, np.uint8)
+        cap = lz.LZ4_compressBound(len(b))
+        dst = np.zeros(max(cap, 16), np.uint8)
+        k = lz.LZ4_compress_default(src.ctypes.data, dst.ctypes.data, len(b), len(dst))
+        assert k > 0, (len(b), k)
+        # the in-tree compressor's output must be a block the real decoder accepts and restores
+        cap2 = abi.lib.crt_lz4_compress_bound(len(b))
+        mine = np.zeros(max(cap2, 16), np.uint8)
+        k2 = abi.lib.crt_lz4_compress(src.ctypes.data, len(b), mine.ctypes.data, cap2)
+        assert k2 > 0, (len(b), k2)
+        back = np.zeros(max(len(b), 1), np.uint8)
+        got = lz.LZ4_decompress_safe(mine.ctypes.data, back.ctypes.data, k2, len(b))
+        assert got == len(b) and bytes(back[:len(b)]) == b, f"liblz4 rejects crt_lz4_compress output for a {len(b)}-byte buffer"
+        plain.append(np.frombuffer(b, dtype=np.uint8)); comp.append(dst[:k].copy())
+        p_off.append(p_off[-1] + len(b)); c_off.append(c_off[-1] + k)
+    np.savez_compressed(os.path.join(OUT, "lz4_vectors.npz"),
+                        plain=np.concatenate(plain), plain_off=np.array(p_off, np.int64),
+                        block=np.concatenate(comp), block_off=np.array(c_off, np.int64),
+                        liblz4_version=np.frombuffer(lz.LZ4_versionString(), dtype=np.uint8))
+    print("lz4_vectors.npz", len(bufs), "buffers, liblz4", lz.LZ4_versionString().decode(), os.path.getsize(os.path.join(OUT, "lz4_vectors.npz")), "bytes;",
+          "liblz4 decodes every crt_lz4_compress block")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "lz4":      # only the LZ4 vectors (the other fixtures are byte-stable and already committed)
+        lz4_vectors()
+        sys.exit(0)
     bake_mesh("monkey_smooth")
     bake_mesh("cirno_low")
     bake_texture("earthmap.png", "earthmap.tx", (512, 256))
     oracle_vectors()
+    lz4_vectors()
