@@ -169,6 +169,9 @@ CRT_DEV void test_leaf(const DeviceScene &sc, V3 o, V3 d, uint32_t first, uint32
         for (uint32_t i = 0; i < n; i++) {
             const float4 *p = sc.tri_pack + 3 * (size_t)(first + i);
             float4 a = p[0], b = p[1], c = p[2];
+            // all 48 bytes are requested together: left alone the compiler sinks the load of v0 behind the determinant test,
+            // a second dependent round trip in every leaf step (the line is in L1 by then, the wave waits all the same)
+            asm volatile("" :: "v"(a.x), "v"(a.y), "v"(a.z));
             float t, beta, gamma, invDet;
             if (tri_t(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, beta, gamma, invDet)) {
                 uint32_t id = f2u(c.y);

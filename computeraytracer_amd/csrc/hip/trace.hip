@@ -277,6 +277,7 @@ template <bool SPILL> struct LaneTrav<false, SPILL> {          // sibling-pair B
     static constexpr int kSpill = kSpillStack;
     Traversal tr;
     CRT_DEV void begin(V3 o, V3 d) { trav_begin(tr, o, d); }
+    CRT_DEV void set_tmax(float t) { tr.best_t = t; tr.tfar = t * 1.000004f; }
     CRT_DEV bool at_leaf() const { return (tr.cur & kLeafTag) != 0; }
     template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, const uint8_t *, Entry *stack, Entry *spill, int depth, Counts &c) { return trav_inner<COUNT>(sc, tr, stack, 256, spill, depth, c); }
     template <bool COUNT, bool EXT> CRT_DEV bool leaf(const DeviceScene &sc, const uint8_t *, Entry *stack, Entry *spill, int depth, Counts &c) { return trav_leaf<COUNT, EXT>(sc, tr, stack, 256, spill, depth, c); }
@@ -286,6 +287,7 @@ template <bool SPILL> struct LaneTrav<true, SPILL> {           // 8-wide quantis
     static constexpr int kSpill = SPILL ? kWideSpill : 1;
     WideTrav tr;
     CRT_DEV void begin(V3 o, V3 d) { wide_begin(tr, o, d); }
+    CRT_DEV void set_tmax(float t) { tr.best_t = t; }
     CRT_DEV bool at_leaf() const { return (tr.cur & kLeafTag) != 0; }
     template <bool COUNT> CRT_DEV bool inner(const DeviceScene &sc, const uint8_t *order, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_inner<COUNT, SPILL>(sc.wide, sc.wide_links, order, tr, stack, 256, spill, depth, c); }
     template <bool COUNT, bool EXT> CRT_DEV bool leaf(const DeviceScene &sc, const uint8_t *order, Entry *stack, Entry *spill, int depth, Counts &c) { return wide_leaf<COUNT, SPILL, EXT>(sc, order, tr, stack, 256, spill, depth, c); }
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
                     if (f2u(d4.w) == kDeadPixel) q.hit[slot] = make_uint2(f2u(kInf), kIdMiss);
                     else {
                         lt.begin(mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z));
-                        if (QUERY) { lt.tr.best_t = o4.w; lt.tr.tfar = o4.w * 1.000004f; }
+                        if (QUERY) lt.set_tmax(o4.w);
                         busy = true;
                     }
                 }
@@ -583,7 +585,7 @@ __global__ __launch_bounds__(256, (FIRST ? CRT_FIRST_WAVES : kPrimaryWaves)) voi
             if (alone) {      // (as a separate, non-inlined function this costs 126 instead of 96 VGPRs)
                 LaneTrav<true, true> lt;
                 lt.tr = tr;
-                lt.tr.cur = 0; lt.tr.g_hdr = 0; lt.tr.g_pend = 0; lt.tr.sp = 0; lt.tr.tfar = tr.best_t * 1.000004f;
+                lt.tr.cur = 0; lt.tr.g_hdr = 0; lt.tr.g_pend = 0; lt.tr.sp = 0;
                 uint2 spill[kWideSpill];
                 Counts cnt = {0, 0};
                 bool more = active;

@@ -131,6 +131,54 @@ __global__ __launch_bounds__(256, 6) void k_g(const float4 *t, const uint32_t *s
     out[g] = acc;
 }
 
+// H: quad-cooperative, straight into LDS: in round r the four lanes of a quad load the four 16-byte quarters of the record of
+// quad lane r with global_load_lds_dwordx4 (one contiguous 64-byte request per quad; destination = the wave's staging row r,
+// lane-linear), so the record of lane L ends up contiguous in row L & 3 at slot L & ~3: four ds_read_b128, no transpose, no
+// VGPR destination for the loads.  Rows are 1040 bytes apart (one 16-byte pad) so that the four lanes of a quad read
+// different banks.  ACT: only lanes with (lane * 7 + step) % 5 < 3 (60 %) take a step; a round whose owner lane rests is
+// skipped by its quad (what a traversal kernel with divergent lanes would do).
+template <bool ACT>
+__global__ __launch_bounds__(256, 6) void k_h(const float4 *t, const uint32_t *start, int steps, float *out) {
+    __shared__ float4 s_x[4][4][65];
+    uint32_t g = blockIdx.x * 256 + threadIdx.x, cur = start[g];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, q = lane & 3u, qbase = lane & ~3u;
+    float acc = 0.0f;
+    for (int i = 0; i < steps; i++) {
+        const bool act = !ACT || (lane * 7u + (uint32_t)i) % 5u < 3u;
+        const uint32_t want = act ? cur : 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t c = (uint32_t)__shfl((int)want, (int)(qbase + r));
+            if (c != 0xFFFFFFFFu) __builtin_amdgcn_global_load_lds((const void *)(t + 4 * (size_t)c + q), (__attribute__((address_space(3))) void *)&s_x[wave][r][0], 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (act) {
+            const float4 *row = &s_x[wave][q][qbase];
+            float4 a = row[0], b = row[1], c = row[2], d = row[3];
+            acc += consume(a, b, c, d, acc);
+            cur = __float_as_uint(a.w);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    out[g] = acc;
+}
+
+// A with the same 60 % lane activity as k_h<true>
+__global__ __launch_bounds__(256, 6) void k_a_act(const float4 *t, const uint32_t *start, int steps, float *out) {
+    uint32_t g = blockIdx.x * 256 + threadIdx.x, cur = start[g];
+    const uint32_t lane = threadIdx.x & 63u;
+    float acc = 0.0f;
+    for (int i = 0; i < steps; i++) {
+        if ((lane * 7u + (uint32_t)i) % 5u < 3u) {
+            const float4 *p = t + 4 * (size_t)cur;
+            float4 a = p[0], b = p[1], c = p[2], d = p[3];
+            acc += consume(a, b, c, d, acc);
+            cur = __float_as_uint(a.w);
+        }
+    }
+    out[g] = acc;
+}
+
 int main(int argc, char **argv) {
     const uint32_t n = argc > 1 ? atoi(argv[1]) : 225000;     // records (64 B each)
     const int steps = argc > 2 ? atoi(argv[2]) : 256;
@@ -154,7 +202,8 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     struct V { const char *name; void (*k)(const float4 *, const uint32_t *, int, float *); } vs[] = {
         {"A 4 x b128 own record", k_a}, {"C b128, wait, 3 x b128", k_c}, {"D quad-cooperative + LDS transpose", k_d}, {"E pair-cooperative + DPP swap", k_e},
-        {"F 2 x b128 (32-byte record)", k_f}, {"G b128 + 3 nontemporal b128", k_g}};
+        {"F 2 x b128 (32-byte record)", k_f}, {"G b128 + 3 nontemporal b128", k_g}, {"H quad-cooperative, direct to LDS", k_h<false>},
+        {"A at 60 % lane activity (x0.6)", k_a_act}, {"H at 60 % lane activity (x0.6)", k_h<true>}};
     for (auto &v : vs) {
         for (int rep = 0; rep < 2; rep++) {
             CK(hipEventRecord(e0));
