@@ -181,17 +181,38 @@ WORKLOADS = {
     "grid10m_1080p": ("grid10m", 1920, 1080, "10M-triangle instanced grid, per-frame LBVH rebuild"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_TLANEOPS = 1024 * 16 * 2.4e9 / 1e12   # 256 CUs x 4 SIMDs x 16 lanes per clock at 2.4 GHz = 39.3 T lane-instructions/s
-PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")   # tools/pmc_to_json.py over the rocprofv3 --pmc passes of this command
+CLOCK_HZ = 2.4e9
+N_SIMD = 1024           # 256 CUs x 4 SIMDs
+# VALU issue ceiling.  tools/ubench_valu.hip (profiles/r03_ubench_valu.txt) measured two issue classes on gfx950: fp32
+# add / sub / mul / fma, v_mov and v_and / or / xor issue every ~2 cycles per SIMD once several waves are resident (the
+# guide's "SIMD-32"), every other VALU instruction (v_cvt_f32_ubyteN, v_pk_fma_f32, min / max[3], compares, selects,
+# shifts) every ~4.  A kernel's ceiling follows from its mix (tools/valu_mix.py -> profiles/r03_valu_mix.json); without
+# that file the all-slow-class rate is used (0.2447 wave-instructions per clock and SIMD = 15.7 lanes).
+VALU_SLOW_RATE = 0.2447
+PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")   # tools/pmc_to_json.py over the rocprofv3 --pmc passes of this command
+MIX_JSON = os.path.join(ROOT, "profiles", "r03_valu_mix.json")
+
+
+def valu_peak_tlaneops(kernel):
+    """(peak in T lane-instructions/s, wave-instructions per clock and SIMD it corresponds to, where it comes from)."""
+    try:
+        m = json.load(open(MIX_JSON))
+        c = m["kernels"][kernel]["issue_ceiling_instr_per_clk_simd"]
+        src = "profiles/r03_valu_mix.json (static mix x measured class rates)" + ("" if m.get("code_rev") == abi.code_rev() else "; STALE: kernel sources changed since")
+    except (OSError, ValueError, KeyError):
+        c, src = VALU_SLOW_RATE, "all instructions in the 4-cycle class (profiles/r03_ubench_valu.txt)"
+    return N_SIMD * 64.0 * c * CLOCK_HZ / 1e12, c, src
 
 
 def pmc_counters(kernel_prefix):
     """What the committed PMC passes say about a kernel (a separate rocprofv3 --pmc run of this same command: counters
     cannot be read from inside the benchmark), per launch and per ray of THAT run: HBM-side bytes, VALU instructions
     issued (SQ_INSTS_VALU) and lanes that were live in them (SQ_THREAD_CYCLES_VALU), resident waves, L2 hit rate, busy
-    fraction of the vector-memory address unit (TA).  {} when the file is missing."""
+    fraction of the vector-memory address unit (TA).  {} when the file is missing.  "stale": the kernel sources have
+    changed since the counters were taken (code_rev in the file vs. the sources beside this script)."""
     try:
-        ks = json.load(open(PMC_JSON))["kernels"]
+        doc = json.load(open(PMC_JSON))
+        ks = doc["kernels"]
     except (OSError, ValueError, KeyError):
         return {}
     best = None
@@ -200,26 +221,27 @@ def pmc_counters(kernel_prefix):
             best = d
     if best is None:
         return {}
-    out = {"traffic": best["hbm_traffic_bytes_per_dispatch"], "l2_hit_rate": best.get("l2_hit_rate")}
+    out = {"traffic": best["hbm_traffic_bytes_per_dispatch"], "l2_hit_rate": best.get("l2_hit_rate"),
+           "stale": doc.get("code_rev") is None or doc.get("code_rev") != abi.code_rev()}
     c = best.get("counters_per_dispatch", {})
     cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0            # summed over the 8 XCDs
     if cyc > 0 and c.get("SQ_INSTS_VALU"):
         out["cycles"] = cyc
-        out["valu_issue_frac"] = round(c["SQ_INSTS_VALU"] / (1024.0 * cyc / 4.0), 3)          # a wave64 VALU instruction occupies its SIMD16 for 4 cycles
+        out["valu_instr_per_clk_simd"] = round(c["SQ_INSTS_VALU"] / (N_SIMD * cyc), 4)
         out["valu_lanes_live_frac"] = round(c.get("SQ_THREAD_CYCLES_VALU", 0.0) / c["SQ_INSTS_VALU"] / 64.0, 3)
-        out["valu_useful_frac"] = round(c.get("SQ_THREAD_CYCLES_VALU", 0.0) / (1024.0 * 16.0 * cyc), 4)   # live lanes / lane slots of all SIMDs
         out["valu_lane_instr"] = c.get("SQ_THREAD_CYCLES_VALU", 0.0)
+        out["valu_instr"] = c["SQ_INSTS_VALU"]
         out["waves_per_simd"] = round(c.get("SQ_WAVE_CYCLES", 0.0) * 4.0 / cyc / 1024.0, 2)
         if c.get("TA_BUSY_avr"):
             out["ta_busy_frac"] = round(c["TA_BUSY_avr"] / cyc, 3)
     return out
 
 
-def kernel_roofline(name, pmc, launch_ms, algorithmic_bytes):
-    """The three figures VERDICT r1 asks for, for one kernel: the roof it is under (useful VALU lane slots), the rate at
-    which it moves its algorithmic bytes (served mostly by L2 / Infinity Cache: NOT an HBM utilisation) and the HBM
-    utilisation proper (PMC traffic / launch time / 8 TB/s).  PMC figures are per launch of the profiled run, which has
-    the same launch size; launch_ms is measured live."""
+def kernel_roofline(name, mix_name, pmc, launch_ms, algorithmic_bytes):
+    """The figures for one kernel: the roof it is under (VALU issue: live lane-instructions per second against the ceiling
+    of its instruction mix), the rate at which it moves its algorithmic bytes (served mostly by L2 / Infinity Cache: NOT
+    an HBM utilisation) and the HBM utilisation proper (PMC traffic / launch time / 8 TB/s).  PMC figures are per launch
+    of the profiled run, which has the same launch size; launch_ms is measured live."""
     out = {"kernel": name, "launch_ms": round(launch_ms, 4)}
     if launch_ms <= 0:
         return out
@@ -228,11 +250,20 @@ def kernel_roofline(name, pmc, launch_ms, algorithmic_bytes):
         out["hbm_GBps"] = round(pmc["traffic"] / (launch_ms * 1e-3) / 1e9, 1)
         out["hbm_frac"] = round(out["hbm_GBps"] / HBM_PEAK_GBS, 4)
     if pmc.get("valu_lane_instr"):
+        peak, ceiling, src = valu_peak_tlaneops(mix_name)
         out["valu_Tlaneops"] = round(pmc["valu_lane_instr"] / (launch_ms * 1e-3) / 1e12, 2)
-        out["valu_useful_frac"] = round(out["valu_Tlaneops"] / VALU_PEAK_TLANEOPS, 4)
-    for k in ("valu_issue_frac", "valu_lanes_live_frac", "waves_per_simd", "l2_hit_rate", "ta_busy_frac"):
+        out["valu_peak_Tlaneops"] = round(peak, 2)
+        out["valu_peak_source"] = src
+        out["valu_useful_frac"] = round(out["valu_Tlaneops"] / peak, 4)
+        # issue rate of the live run against the mix's ceiling, and against the plain fp32-FMA rate of the guide (0.5 / clk)
+        live_rate = pmc["valu_instr"] / (N_SIMD * launch_ms * 1e-3 * CLOCK_HZ)
+        out["valu_instr_per_clk_simd"] = round(live_rate, 4)
+        out["valu_issue_frac"] = round(live_rate / ceiling, 3)
+    for k in ("valu_lanes_live_frac", "waves_per_simd", "l2_hit_rate", "ta_busy_frac"):
         if pmc.get(k) is not None:
             out[k] = pmc[k]
+    if pmc.get("stale"):
+        out["counters_stale"] = True
     return out
 
 
@@ -300,6 +331,7 @@ def main():
     ap.add_argument("--tracer", default=os.environ.get("CRT_TRACER", "wavefront"), choices=["megakernel", "wavefront"])
     ap.add_argument("--spp-per-step", type=int, default=16, help="iterations (samples per pixel) per step; static-scene workloads only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--refit", action="store_true", help="per-frame-rebuild workload only: crt_bvh_refit instead of crt_bvh_build in every frame")
     ap.add_argument("--bvh", default=os.environ.get("CRT_BVH", ""), choices=["", "lbvh", "sah", "collapse", "lbvh-wide", "sah-wide", "direct"],
                     help="default: sah-wide (static scenes), direct (CRT_BVH_WIDE_DIRECT) for the per-frame rebuild workload")
     args = ap.parse_args()
@@ -364,9 +396,12 @@ def main():
         if not rebuild:
             ctx.render(scene.params, first_iter, seeds[first_iter - 1:first_iter - 1 + n * spp])
             return
-        for i in range(n):            # config 5: animate + full rebuild every frame, one sample per frame
+        for i in range(n):            # config 5: animate + full rebuild every frame, one sample per frame; nothing here waits for the GPU
             ctx.animate(float(first_iter + i), 0.35)
-            ctx.build(bvh_flags)
+            if args.refit:
+                ctx.refit()           # crt_bvh_refit: the boxes of the first build's tree follow the triangles
+            else:
+                ctx.build(bvh_flags, wait=False)
             ctx.render(scene.params, 1, seeds[first_iter - 1 + i:first_iter + i])
 
     # V, T, D for the bytes-per-ray model: one instrumented dispatch (untimed)
@@ -409,6 +444,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     st = ctx.stats()
+    if rebuild and not args.refit:
+        build_ms = st.last_build_ms       # the last frame's enqueue-only rebuild (device time, read after the sync)
     rays = float(st.rays)
     kernel_ms = st.last_render_ms     # HIP events on the context's stream around the timed launches (last run() call)
 
@@ -507,7 +544,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "scene": scene_name, "width": W, "height": H, "spp_per_step": spp,
                        "tris": int(len(scene.tris)), "spheres": int(len(scene.spheres)), "quads": int(len(scene.quads)),
-                       "tracer": args.tracer, "bvh": args.bvh, "rng": "ref-hash", "parallelism": f"tile{world}" if world > 1 else "single",
+                       "tracer": args.tracer, "bvh": args.bvh + ("+refit per frame" if rebuild and args.refit else ""), "rng": "ref-hash", "parallelism": f"tile{world}" if world > 1 else "single",
                        "bvh_build_ms": round(build_ms, 4), "gather_ms": None if gather_ms is None else round(gather_ms, 3),
                        "gather": gather_path, "gather_check": gather_check,
                        "rays_per_path": round(D, 3), "nodes_per_ray": round(V, 2), "prim_tests_per_ray": round(T, 2)},
@@ -520,18 +557,26 @@ def main():
         # passes of this same command (profiles/r02_pmc.json) and is attached for the workload they were taken on.
         pmc_ok = args.workload == "lost_empire_4k" and scene_name == "voxel_city" and kernel_name == "k_wf_extend" and args.bvh == "sah-wide"
         pmc = pmc_counters("k_wf_extend<false") if pmc_ok else {}
-        rl = kernel_roofline(kernel_name, pmc, launch_ms, launch_rays * kernel_bytes_per_ray)
+        rl = kernel_roofline(kernel_name, "k_wf_extend", pmc, launch_ms, launch_rays * kernel_bytes_per_ray)
         rl.update({"kernel_bytes_per_ray": round(kernel_bytes_per_ray, 1), "pipeline_bytes_per_ray": round(bytes_per_ray, 1),
                    "launches": int(n_launches), "rays_per_launch": round(launch_rays)})
         if tracer == abi.TRACER_WAVEFRONT and st.last_primary_launches:
-            rl["primary"] = {"kernel": "k_wf_primary" + (" (rays, traversal and shading of bounce 0)" if st.last_shade_launches == st.last_extend_launches else ""),
-                             "launches": int(st.last_primary_launches),
-                             "launch_ms": round(st.last_primary_ms / st.last_primary_launches, 4),
-                             "rays_per_launch": round(float(st.paths) / st.last_primary_launches)}
+            fused = st.last_shade_launches == st.last_extend_launches
+            pm_ms = st.last_primary_ms / st.last_primary_launches
+            pm_rays = float(st.paths) / st.last_primary_launches
+            ppmc = pmc_counters("k_wf_primary<") if pmc_ok else {}
+            # bounce 0 per path: 8-wide nodes and triangles as in the model, no queue entry read (the kernel makes its own camera
+            # rays); shading record 64 B, 48 B written per surviving path, 16 B per ended one
+            prim = kernel_roofline("k_wf_primary" + (" (rays, traversal and shading of bounce 0)" if fused else ""), "k_wf_primary", ppmc, pm_ms,
+                                   pm_rays * (node_b * V + 48.0 * T + 64.0 + 48.0 * (1.0 - 1.0 / D) + 16.0 / D))
+            prim.update({"launches": int(st.last_primary_launches), "rays_per_launch": round(pm_rays)})
+            rl["primary"] = prim
         if rl.get("valu_useful_frac") is not None:
-            line["roofline"] = dict({"bound": "valu-issue", "achieved": rl["valu_Tlaneops"], "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlane-op/s",
+            line["roofline"] = dict({"bound": "valu-issue", "achieved": rl["valu_Tlaneops"], "peak": rl["valu_peak_Tlaneops"], "unit": "Tlane-op/s",
                                      "frac": rl["valu_useful_frac"], "traffic": pmc.get("traffic")}, **rl)
-            line["roofline"]["counters_source"] = "profiles/r02_pmc.json (rocprofv3 --pmc passes of this command)"
+            line["roofline"]["counters_source"] = "profiles/r03_pmc.json (rocprofv3 --pmc passes of this command)"
+            if pmc.get("stale"):
+                line["roofline"]["counters_stale"] = True
         else:
             # no counter passes for this workload / tracer: only the algorithmic-bytes rate is known, and it is NOT an HBM
             # utilisation (the scene lives in L2 / Infinity Cache); reported against the HBM peak as the contract asks
@@ -546,7 +591,7 @@ def main():
             # k_wf_shade launches as k_wf_extend launches and the primary rays are not theirs)
             fused_first = st.last_primary_launches and st.last_shade_launches == st.last_extend_launches
             shade_rays = (float(st.rays) - (float(st.paths) if fused_first else 0.0)) / st.last_shade_launches
-            line["roofline"]["shade"] = kernel_roofline("k_wf_shade", spmc, shade_ms, shade_rays * (56.0 + 64.0 + 48.0 * (1.0 - 1.0 / D) + 16.0 / D))
+            line["roofline"]["shade"] = kernel_roofline("k_wf_shade", "k_wf_shade", spmc, shade_ms, shade_rays * (56.0 + 64.0 + 48.0 * (1.0 - 1.0 / D) + 16.0 / D))
         # BVH build against SURVEY 8(d)'s 376 B / primitive model
         n_prims = int(len(scene.tris) + len(scene.spheres) + len(scene.quads))
         line["build"] = {"ms": round(build_ms, 4), "prims": n_prims, "bytes_per_prim": 376,

@@ -96,6 +96,8 @@ def _load():
         "crt_scene_upload": (i32, [vp, P(SceneDesc)]),
         "crt_extensions_set": (i32, [vp, u32]),
         "crt_bvh_build": (i32, [vp, u32, P(f32)]),
+        "crt_bvh_refit": (i32, [vp, P(f32)]),
+        "crt_poll": (i32, [vp, P(i32)]),
         "crt_tris_update": (i32, [vp, vp, u32, u32]),
         "crt_tris_animate": (i32, [vp, f32, f32]),
         "crt_tris_read": (i32, [vp, vp, u32, u32]),
@@ -180,6 +182,21 @@ def make_quad(corner, u, v, material):
 
 
 COMM_ID_BYTES = 128
+
+
+def code_rev():
+    """A short hash of the tracer's kernel sources (trace.hip and the headers it includes).  The committed counter files
+    under profiles/ carry the value they were collected with; bench.py marks their figures stale when it differs."""
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "hip")
+    h = hashlib.sha256()
+    for f in ("trace.hip", "intersect.h", "intersect_wide.h", "shade.h", "device_math.h", "build_internal.h"):
+        try:
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+        except OSError:
+            return None
+    return h.hexdigest()[:16]
 
 
 def comm_unique_id():
@@ -329,10 +346,31 @@ class Context:
     def extensions_set(self, ext_flags):
         self._check(lib.crt_extensions_set(self._h, ext_flags), "crt_extensions_set")
 
-    def build(self, flags=BVH_LBVH):
+    def build(self, flags=BVH_LBVH, wait=True):
+        """crt_bvh_build.  wait=False passes build_ms = NULL: a CRT_BVH_WIDE_DIRECT rebuild then only enqueues (abi.h) and
+        the build's time is in stats().last_build_ms after the next sync; returns None."""
+        if not wait:
+            self._check(lib.crt_bvh_build(self._h, flags, None), "crt_bvh_build")
+            return None
         ms = C.c_float()
         self._check(lib.crt_bvh_build(self._h, flags, C.byref(ms)), "crt_bvh_build")
         return ms.value
+
+    def refit(self, want_cost=False):
+        """crt_bvh_refit: boxes of the existing 8-wide tree from the primitives as they are now; want_cost waits and returns
+        sum(area(node)) / area(root)."""
+        if not want_cost:
+            self._check(lib.crt_bvh_refit(self._h, None), "crt_bvh_refit")
+            return None
+        c = C.c_float()
+        self._check(lib.crt_bvh_refit(self._h, C.byref(c)), "crt_bvh_refit")
+        return c.value
+
+    def poll(self):
+        """crt_poll: True when everything enqueued so far has finished."""
+        d = C.c_int()
+        self._check(lib.crt_poll(self._h, C.byref(d)), "crt_poll")
+        return bool(d.value)
 
     def animate(self, frame, amplitude):
         self._check(lib.crt_tris_animate(self._h, frame, amplitude), "crt_tris_animate")

@@ -17,6 +17,7 @@ struct BuildInput {            // device pointers to the uploaded arrays (refere
     const crt_tri *tris;       uint32_t n_tris;
 };
 
+constexpr uint32_t kWideMaxLevelsDecl = 64;      // = kWideMaxLevels (declared below)
 struct BuildState {
     uint32_t n_prims = 0, n_pairs = 0;
     const uint32_t *sorted_vals = nullptr;
@@ -41,11 +42,22 @@ struct BuildState {
     bool pairs_valid = false;                        // false after a CRT_BVH_WIDE_DIRECT build: no pair tree, only the 8-wide one
     bool levels_measured = false;                    // level_hist / dp_depth describe the current pairs (bvh_sah.hip: measure_pair_depths)
     uint32_t level_hist[128] = {};                   // pairs per depth (root = 1)
+    // Enqueue-only direct rebuilds (bvh_direct.hip).  A CRT_BVH_WIDE_DIRECT build that may not wait for the GPU launches its
+    // level kernels for the depth of the previous such build of this scene plus two (the kernels read every count from the
+    // device's level table); the table comes back through pinned memory and is looked at by resolve_wide_counts.
+    bool async_request = false;                      // this build may skip every wait (crt_bvh_build with build_ms == NULL)
+    uint32_t direct_hint_n = 0, direct_hint_levels = 0, direct_hint_leaf = 0;
+    uint32_t direct_hint_lc[kWideMaxLevelsDecl + 3] = {};
+    uint32_t *host_lc = nullptr;                     // pinned copy of the device's level table (+ overflow word)
+    hipEvent_t ev_counts = nullptr;
+    bool counts_pending = false;
+    bool records_fresh = false;                      // tri_shade / plo centroids / scene_bounds describe the triangles as they are now (animate_tris wrote them)
 };
 
 constexpr uint32_t kWideStrideF4 = 4;     // 64-byte nodes (what a step loads): two siblings per 128-byte line; the eight links of node i
                                           // live apart, at 32 bytes per node, behind the node array (build_wide / wide_links_of)
 constexpr uint32_t kWideMaxLevels = 64;
+static_assert(kWideMaxLevels == kWideMaxLevelsDecl, "BuildState::direct_hint_lc");
 constexpr uint32_t kWideLeafTag = 0x80000000u;                  // link word of a leaf slot: tag | kind << 29 | (count - 1) << 26 | first slot in the kind's array
 constexpr uint32_t kWideEmptyLink = kWideLeafTag | (3u << 29);  // ... of an empty slot
 constexpr uint32_t kPairLevels = 128;      // bins of the depth histogram (> kMaxPairDepth)
@@ -60,7 +72,13 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err);
 struct PackOut;
 bool build_wide_direct(hipStream_t stream, const BuildInput &in, BuildState &st, const uint64_t *keys, uint32_t idx_bits, const uint32_t *rank_sphere,
                        const uint32_t *rank_quad, const PackOut &out, std::string &err);
-bool animate_tris(hipStream_t stream, uint32_t n, const crt_tri *rest, crt_tri *out, float frame, float amplitude, std::string &err);
+// After an enqueue-only direct build: waits for its level table and takes node count, depth and the next build's hint
+// from it.  overflow: the tree was deeper than the launches planned for (parts were dropped: the BVH is not usable).
+bool resolve_wide_counts(BuildState &st, bool &overflow, std::string &err);
+// Boxes of the existing 8-wide tree recomputed bottom-up from the primitives as they are now (crt_bvh_refit); topology,
+// leaf contents and primitive order stay.  cost_dev (optional): receives sum over nodes of area(node), and area(root) in [1].
+bool refit_wide(hipStream_t stream, const BuildInput &in, BuildState &st, float *cost_dev, std::string &err);
+bool animate_tris(hipStream_t stream, uint32_t n, const crt_tri *rest, crt_tri *out, float frame, float amplitude, BuildState *st, std::string &err);
 void free_build_state(BuildState &st);
 
 // ---- tracing (trace.hip) ----

@@ -24,6 +24,7 @@
 #include "build_internal.h"
 #include "bvh_common.h"
 #include "bvh_pack.h"
+#include "bvh_wide_node.h"
 
 namespace crt {
 
@@ -59,8 +60,12 @@ __device__ __forceinline__ uint32_t dw_find_cut(const uint64_t *keys, uint32_t b
 
 // One node: range -> up to eight parts -> slots, header word, leaf references, queue entries of the inner parts.
 // Every lane of the node's group computes the same values; lane gl == 0 writes.
+// cap: this is the last level the host has launches for (enqueue-only rebuild, build_wide_direct): a part that would need
+// another level is dropped (empty slot) and the overflow word is set; the host reads it at the next crt_sync and reports
+// the tree as invalid (the hint it planned with is the depth of the previous build plus two, so this is a scene whose
+// shape changed abruptly between two frames).
 template <int LANES>
-__device__ __forceinline__ void dw_split_node(const DwSplit &A, uint32_t level, uint32_t next_base, uint2 range, uint32_t id, uint2 *q_out, uint32_t gl, uint32_t gbase) {
+__device__ __forceinline__ void dw_split_node(const DwSplit &A, uint32_t level, uint32_t next_base, uint2 range, uint32_t id, uint2 *q_out, uint32_t gl, uint32_t gbase, bool cap) {
     uint32_t sb[8], se[8], sd[8];       // part k: keys [sb, se); sd: bits 0..2 side per axis, bits 3..5 "axis was cut"
 #pragma unroll
     for (int k = 0; k < 8; k++) { sb[k] = 0; se[k] = 0; sd[k] = 0; }
@@ -131,6 +136,12 @@ __device__ __forceinline__ void dw_split_node(const DwSplit &A, uint32_t level, 
     uint32_t imask = 0, n_inner = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) if (k < n && se[k] - sb[k] > A.leaf_max) { imask |= 1u << ((slot_of >> (4 * k)) & 7u); n_inner++; }
+    if (cap && n_inner) {
+        if (gl == 0u) atomicOr(&A.level_count[kWideMaxLevels + 2], 1u);
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (k < n && se[k] - sb[k] > A.leaf_max) se[k] = sb[k];      // dropped: reads as an empty slot below
+        imask = 0; n_inner = 0;
+    }
     uint32_t qpos = 0;
     if (n_inner && gl == 0u) qpos = atomicAdd(&A.level_count[level + 1], n_inner);
     if (LANES > 1) qpos = (uint32_t)__shfl((int)qpos, (int)gbase);
@@ -143,6 +154,7 @@ __device__ __forceinline__ void dw_split_node(const DwSplit &A, uint32_t level, 
         if (k >= n) continue;
         const uint32_t sl = (slot_of >> (4 * k)) & 7u, sz = se[k] - sb[k];
         uint32_t r;
+        if (sz == 0u) continue;
         if (sz > A.leaf_max) {
             const uint32_t rank = (uint32_t)__builtin_popcount(imask & ((1u << sl) - 1u));      // inner children are numbered in slot order
             if (gl == 0u) q_out[qpos + rank] = make_uint2(sb[k], se[k]);
@@ -160,7 +172,7 @@ __device__ __forceinline__ void dw_split_node(const DwSplit &A, uint32_t level, 
 
 // level_count[l] = nodes of level l; level l reads queue l & 1 and appends to the other one.  Node ids are BFS: the
 // nodes of level l are next_base - n_in + [0, n_in).
-__global__ __launch_bounds__(256) void k_dw_split(DwSplit A, uint32_t level, const uint2 *q_in, uint2 *q_out) {
+__global__ __launch_bounds__(256) void k_dw_split(DwSplit A, uint32_t level, const uint2 *q_in, uint2 *q_out, bool cap) {
     const uint32_t n_in = A.level_count[level];
     uint32_t next_base = 0;
     for (uint32_t l = 0; l <= level; l++) next_base += A.level_count[l];
@@ -169,14 +181,14 @@ __global__ __launch_bounds__(256) void k_dw_split(DwSplit A, uint32_t level, con
     // than the shorter searches save (8 lanes per node at 250 k nodes: 357 instead of 115 us).
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, n_threads = gridDim.x * blockDim.x, lane = threadIdx.x & 63u;
     if (n_in <= 512u) {
-        for (uint32_t i = tid >> 6; i < n_in; i += n_threads >> 6) dw_split_node<64>(A, level, next_base, q_in[i], next_base - n_in + i, q_out, lane, 0u);
+        for (uint32_t i = tid >> 6; i < n_in; i += n_threads >> 6) dw_split_node<64>(A, level, next_base, q_in[i], next_base - n_in + i, q_out, lane, 0u, cap);
     } else {
-        for (uint32_t i = tid; i < n_in; i += n_threads) dw_split_node<1>(A, level, next_base, q_in[i], next_base - n_in + i, q_out, 0u, 0u);
+        for (uint32_t i = tid; i < n_in; i += n_threads) dw_split_node<1>(A, level, next_base, q_in[i], next_base - n_in + i, q_out, 0u, 0u, cap);
     }
 }
 
 __global__ void k_dw_init(uint32_t *level_count, uint32_t n_levels, uint2 *q0, uint32_t n) {
-    for (uint32_t i = threadIdx.x; i <= n_levels; i += blockDim.x) level_count[i] = i == 0 ? 1u : 0u;
+    for (uint32_t i = threadIdx.x; i <= n_levels + 1u; i += blockDim.x) level_count[i] = i == 0 ? 1u : 0u;      // [n_levels + 1] = the overflow word
     if (threadIdx.x == 0) q0[0] = make_uint2(0u, n);
 }
 
@@ -188,105 +200,46 @@ struct DwEmit {
 
 // Eight lanes per node, one per slot: the leaf primitives of a node are consecutive sorted positions, so a group's
 // gathers and record writes run side by side and coalesce; the node box and the packed plane bytes are reduced over the
-// group with shuffles.
-__device__ __forceinline__ uint32_t or_quad(uint32_t v) {      // OR over the four lanes of a quad
-    v |= (uint32_t)__shfl_xor((int)v, 1); v |= (uint32_t)__shfl_xor((int)v, 2);
-    return v;
-}
-__global__ __launch_bounds__(256) void k_dw_emit(DwEmit A, uint32_t first_id, uint32_t count) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t sl = t & 7u;
-    const bool active = (t >> 3) < count;               // whole groups are active or not
-    const uint32_t id = first_id + (active ? (t >> 3) : 0u);
-    const uint32_t hdr = ((const uint32_t *)(A.wide + (size_t)kWideStrideF4 * id))[3];
-    const uint32_t imask = hdr & 0xFFu, child_base = hdr >> 8;
-    const uint32_t ref = ((const uint32_t *)A.links)[8 * (size_t)id + sl];
-    float clo[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f}, chi[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
-    uint32_t link = ref;
-    bool valid = false;
-    if (active) {
-        if ((imask >> sl) & 1u) {
-            const uint32_t cid = child_base + (uint32_t)__builtin_popcount(imask & ((1u << sl) - 1u));
-            const float4 a = A.box[2 * (size_t)cid], b = A.box[2 * (size_t)cid + 1];
-            clo[0] = a.x; clo[1] = a.y; clo[2] = a.z; chi[0] = b.x; chi[1] = b.y; chi[2] = b.z;
-            valid = true;
-        } else if (ref != kWideEmptyLink) {
-            const uint32_t s0 = ref & ((1u << 26) - 1u), cnt = ((ref >> 26) & 7u) + 1u;
-            uint32_t kind0 = 0, slot0 = 0;
-            for (uint32_t j = 0; j < cnt; j++) {
-                uint32_t kind, slot; float lo[3], hi[3];
-                pack_prim<true>(A.in, A.n, s0 + j, (uint32_t)A.keys[s0 + j] & A.idx_mask, A.rank_sphere, A.rank_quad, A.tri_shade, A.out, kind, slot, lo, hi);
-                if (j == 0) { kind0 = kind; slot0 = slot; }
+// group with shuffles (wide_node_finish, bvh_wide_node.h).  The level's node count and first id come from the device's
+// level table, and the groups are dealt grid-stride, so the host can launch this without knowing either.
+__global__ __launch_bounds__(256) void k_dw_emit(DwEmit A, const uint32_t *level_count, uint32_t level) {
+    const uint32_t count = level_count[level];
+    uint32_t first_id = 0;
+    for (uint32_t l = 0; l < level; l++) first_id += level_count[l];
+    const uint32_t sl = threadIdx.x & 7u;
+    for (uint32_t g0 = blockIdx.x * 32u; g0 < count; g0 += gridDim.x * 32u) {      // block-uniform trip count: whole groups are active or not
+        const uint32_t grp = g0 + (threadIdx.x >> 3);
+        const bool active = grp < count;
+        const uint32_t id = first_id + (active ? grp : 0u);
+        const uint32_t hdr = ((const uint32_t *)(A.wide + (size_t)kWideStrideF4 * id))[3];
+        const uint32_t imask = hdr & 0xFFu, child_base = hdr >> 8;
+        const uint32_t ref = ((const uint32_t *)A.links)[8 * (size_t)id + sl];
+        float clo[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f}, chi[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
+        uint32_t link = ref;
+        bool valid = false;
+        if (active) {
+            if ((imask >> sl) & 1u) {
+                const uint32_t cid = child_base + (uint32_t)__builtin_popcount(imask & ((1u << sl) - 1u));
+                const float4 a = A.box[2 * (size_t)cid], b = A.box[2 * (size_t)cid + 1];
+                clo[0] = a.x; clo[1] = a.y; clo[2] = a.z; chi[0] = b.x; chi[1] = b.y; chi[2] = b.z;
+                valid = true;
+            } else if (ref != kWideEmptyLink) {
+                const uint32_t s0 = ref & ((1u << 26) - 1u), cnt = ((ref >> 26) & 7u) + 1u;
+                uint32_t kind0 = 0, slot0 = 0;
+                for (uint32_t j = 0; j < cnt; j++) {
+                    uint32_t kind, slot; float lo[3], hi[3];
+                    pack_prim<true>(A.in, A.n, s0 + j, (uint32_t)A.keys[s0 + j] & A.idx_mask, A.rank_sphere, A.rank_quad, A.tri_shade, A.out, kind, slot, lo, hi);
+                    if (j == 0) { kind0 = kind; slot0 = slot; }
 #pragma unroll
-                for (int a = 0; a < 3; a++) { clo[a] = fminf(clo[a], lo[a]); chi[a] = fmaxf(chi[a], hi[a]); }
+                    for (int a = 0; a < 3; a++) { clo[a] = fminf(clo[a], lo[a]); chi[a] = fmaxf(chi[a], hi[a]); }
+                }
+                link = kWideLeafTag | (kind0 << 29) | ((cnt - 1u) << 26) | slot0;
+                valid = true;
             }
-            link = kWideLeafTag | (kind0 << 29) | ((cnt - 1u) << 26) | slot0;
-            valid = true;
         }
+        wide_node_finish(active, sl, id, hdr, clo, chi, valid, A.wide, A.box, nullptr);
+        if (active) ((uint32_t *)A.links)[8 * (size_t)id + sl] = link;
     }
-    // node box over the group (a NaN coordinate of a primitive stays in its own slot's box: fminf / fmaxf drop it here,
-    // and the slot's quantisation below maps it to the full range)
-    float lo[3], hi[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        float l = clo[a], h = chi[a];
-#pragma unroll
-        for (int off = 1; off < 8; off <<= 1) { l = fminf(l, __shfl_xor(l, off)); h = fmaxf(h, __shfl_xor(h, off)); }
-        lo[a] = l; hi[a] = h;
-    }
-    const bool any = __builtin_popcount((uint32_t)((__ballot(valid) >> (threadIdx.x & 56u)) & 0xFFull)) != 0;
-    if (!any) { for (int a = 0; a < 3; a++) { lo[a] = 0.0f; hi[a] = 0.0f; } }
-    // origin (rounded down to 15 mantissa bits) and per-axis grid step: wide_emit's arithmetic (bvh_wide.hip)
-    float origin[3], inv_scale[3]; uint32_t ebits[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        uint32_t b = __float_as_uint(lo[a]), tr = b & 0xFFFFFE00u;
-        if ((b & 0x80000000u) && tr != b) tr += 0x200u;          // negative: truncation moved it up, step one unit down
-        origin[a] = __uint_as_float(tr);
-        const float ext = hi[a] - origin[a];
-        int e = -100;
-        if (ext > 0.0f) {
-            int x; const float m = frexpf(ext / 255.0f, &x);
-            e = m > 0.999999f ? x + 1 : x;
-        }
-        if (!(ext <= 3.402823466e38f)) e = 122;
-        e = e < -100 ? -100 : e > 122 ? 122 : e;
-        ebits[a] = (uint32_t)(e + 127);
-        inv_scale[a] = __uint_as_float((uint32_t)(127 - e) << 23);
-    }
-    // this slot's six plane bytes, shifted to their place in the slot's dword; empty slots keep qlo = 255, qhi = 0
-    const uint32_t sh = 8u * (sl & 3u);
-    uint32_t w[6];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        float fl = 255.0f, fh = 0.0f;
-        if (valid) {
-            const float xl = (clo[a] - origin[a]) * inv_scale[a], xh = (chi[a] - origin[a]) * inv_scale[a];
-            fl = floorf(xl - 0.0009765625f); fh = ceilf(xh + 0.0009765625f);
-            fl = (fl >= 0.0f && fl <= 255.0f) ? fl : 0.0f;
-            fh = (fh >= 0.0f && fh <= 255.0f) ? fh : 255.0f;
-        }
-        w[a] = (uint32_t)fl << sh; w[3 + a] = (uint32_t)fh << sh;
-    }
-    uint32_t mine[6], other[6];      // the dword of this lane's quad (slots 0-3 or 4-7) and the other quad's
-#pragma unroll
-    for (int k = 0; k < 6; k++) { mine[k] = or_quad(w[k]); other[k] = (uint32_t)__shfl_xor((int)mine[k], 4); }
-    if (!active) return;
-    const bool upper = sl >= 4u;
-    uint32_t q[6][2];
-#pragma unroll
-    for (int k = 0; k < 6; k++) { q[k][0] = upper ? other[k] : mine[k]; q[k][1] = upper ? mine[k] : other[k]; }
-    ((uint32_t *)A.links)[8 * (size_t)id + sl] = link;
-    float4 *o = A.wide + (size_t)kWideStrideF4 * id;
-    if (sl == 0u) {
-        o[0] = make_float4(__uint_as_float(__float_as_uint(origin[0]) | ebits[0]), __uint_as_float(__float_as_uint(origin[1]) | ebits[1]),
-                           __uint_as_float(__float_as_uint(origin[2]) | ebits[2]), __uint_as_float(hdr));
-        A.box[2 * (size_t)id] = make_float4(lo[0], lo[1], lo[2], 0.0f);
-    } else if (sl == 1u) {
-        o[1] = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
-        A.box[2 * (size_t)id + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
-    } else if (sl == 2u) o[2] = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
-    else if (sl == 3u) o[3] = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
 }
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return false; } } while (0)
@@ -297,6 +250,20 @@ static bool ensure_d(DeviceBuffer &b, size_t bytes, std::string &err) {
     size_t want = bytes < 256 ? 256 : bytes;
     HIP_TRY(hipMalloc(&b.ptr, want));
     b.bytes = want;
+    return true;
+}
+
+bool resolve_wide_counts(BuildState &st, bool &overflow, std::string &err) {
+    overflow = false;
+    if (!st.counts_pending) return true;
+    HIP_TRY(hipEventSynchronize(st.ev_counts));
+    st.counts_pending = false;
+    const uint32_t *h = st.host_lc;
+    overflow = h[kWideMaxLevels + 2] != 0u;
+    st.n_wide = 0; st.wide_levels = 0;
+    for (uint32_t l = 0; l <= kWideMaxLevels && h[l]; l++) { st.n_wide += h[l]; st.wide_levels = l + 1; st.direct_hint_lc[l] = h[l]; }
+    for (uint32_t l = st.wide_levels; l < kWideMaxLevels + 3; l++) st.direct_hint_lc[l] = 0;
+    st.direct_hint_levels = overflow ? 0u : st.wide_levels;      // after an overflow the next build counts its levels the slow way
     return true;
 }
 
@@ -313,34 +280,62 @@ bool build_wide_direct(hipStream_t stream, const BuildInput &in, BuildState &st,
     if (!ensure_d(st.wide_queue[0], (size_t)st.n_pairs * 8, err) || !ensure_d(st.wide_queue[1], (size_t)st.n_pairs * 8, err)) return false;
     if (!ensure_d(st.wide_levels_dev, (kWideMaxLevels + 3) * 4, err)) return false;
     if (!ensure_d(st.nlo, (size_t)st.n_pairs * 2 * sizeof(float4), err)) return false;
+    if (!st.host_lc) HIP_TRY(hipHostMalloc((void **)&st.host_lc, (kWideMaxLevels + 3) * 4, hipHostMallocDefault));
+    if (!st.ev_counts) HIP_TRY(hipEventCreateWithFlags(&st.ev_counts, hipEventDisableTiming));
     uint32_t *lc = (uint32_t *)st.wide_levels_dev.ptr;
     const bool single_kind = in.n_spheres == n || in.n_quads == n || in.n_tris == n;
     static const uint32_t env_leaf = [] { const char *e = getenv("CRT_DW_LEAF"); int v = e ? atoi(e) : 2; return (uint32_t)(v < 1 ? 1 : v > 8 ? 8 : v); }();
     DwSplit S{keys, idx_bits, single_kind ? env_leaf : 1u, lc, (float4 *)st.wide.ptr, (uint32_t *)links};
+    DwEmit E{keys, (uint32_t)((1ull << idx_bits) - 1ull), n, in, rank_sphere, rank_quad, (const float4 *)st.tri_shade.ptr, out,
+             (float4 *)st.wide.ptr, links, (float4 *)st.nlo.ptr};
     hipLaunchKernelGGL(k_dw_init, dim3(1), dim3(128), 0, stream, lc, kWideMaxLevels + 1, (uint2 *)st.wide_queue[0].ptr, n);
     const uint32_t grid = std::min<uint32_t>(2048u, (st.n_pairs + 255u) / 256u);
-    uint32_t host_lc[kWideMaxLevels + 3];
+    // Enqueue-only: a rebuild of the scene the previous direct build saw (same primitive count and leaf size) replays
+    // that build's launch plan two levels deeper, nothing is read back before the launches: crt_tris_animate ->
+    // crt_bvh_build -> crt_dispatch is one stream of launches, the host never waits.  The level kernels take
+    // their counts from the device's table; the last planned level cannot open another one (k_dw_split's cap).
+    if (st.async_request && st.direct_hint_levels && st.direct_hint_n == n && st.direct_hint_leaf == S.leaf_max) {
+        int slack = 2;
+        if (const char *e = getenv("CRT_DW_PLAN_SLACK")) slack = atoi(e);      // test hook (read per build): a negative slack forces the overflow path
+        const uint32_t L = (uint32_t)std::min<int>(std::max<int>((int)st.direct_hint_levels + slack, 1), (int)kWideMaxLevels);
+        for (uint32_t level = 0; level < L; level++)
+            hipLaunchKernelGGL(k_dw_split, dim3(grid), dim3(256), 0, stream, S, level, (const uint2 *)st.wide_queue[level & 1].ptr, (uint2 *)st.wide_queue[(level & 1) ^ 1].ptr, level + 1u == L);
+        for (uint32_t l = L; l-- > 0;) {
+            // grid from the previous build's level sizes with a quarter to spare; the kernel is grid-stride, so a level that
+            // grew beyond that is still complete
+            const uint32_t guess = st.direct_hint_lc[l] + st.direct_hint_lc[l] / 4u + 64u;
+            hipLaunchKernelGGL(k_dw_emit, dim3(std::min<uint32_t>((guess + 31u) / 32u, 65536u)), dim3(256), 0, stream, E, (const uint32_t *)lc, l);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(st.host_lc, lc, (kWideMaxLevels + 3) * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(st.ev_counts, stream));
+        st.counts_pending = true;
+        st.n_wide = 0;
+        for (uint32_t l = 0; l < kWideMaxLevels; l++) st.n_wide += st.direct_hint_lc[l];      // the previous build's count until this one's is known (only "non-zero" matters to the tracer)
+        st.wide_levels = L;                                                                 // an upper bound: what the tracer sizes its stacks by
+        return true;
+    }
     uint32_t level = 0;
+    uint32_t *host_lc = st.host_lc;
     for (;;) {
         // blind launches (an empty level costs ~5 us): the depth of a balanced tree plus two the first time, four more after a miss
         uint32_t expect = 2;
         for (uint64_t cap = 8ull * S.leaf_max; cap < n; cap *= 8ull) expect++;
         const uint32_t chunk_end = std::min<uint32_t>(level == 0 ? expect + 1u : level + 4u, kWideMaxLevels);
         for (; level < chunk_end; level++)
-            hipLaunchKernelGGL(k_dw_split, dim3(grid), dim3(256), 0, stream, S, level, (const uint2 *)st.wide_queue[level & 1].ptr, (uint2 *)st.wide_queue[(level & 1) ^ 1].ptr);
+            hipLaunchKernelGGL(k_dw_split, dim3(grid), dim3(256), 0, stream, S, level, (const uint2 *)st.wide_queue[level & 1].ptr, (uint2 *)st.wide_queue[(level & 1) ^ 1].ptr, false);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(host_lc, lc, (kWideMaxLevels + 3) * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (host_lc[level] == 0) break;
         if (level >= kWideMaxLevels) { err = "wide BVH deeper than 64 levels"; return false; }
     }
-    uint32_t start[kWideMaxLevels + 2];
-    start[0] = 0;
-    for (uint32_t l = 0; l <= kWideMaxLevels && host_lc[l]; l++) { start[l + 1] = start[l] + host_lc[l]; st.n_wide += host_lc[l]; st.wide_levels = l + 1; }
-    DwEmit E{keys, (uint32_t)((1ull << idx_bits) - 1ull), n, in, rank_sphere, rank_quad, (const float4 *)st.tri_shade.ptr, out,
-             (float4 *)st.wide.ptr, links, (float4 *)st.nlo.ptr};
+    for (uint32_t l = 0; l < kWideMaxLevels + 3; l++) st.direct_hint_lc[l] = 0;
+    for (uint32_t l = 0; l <= kWideMaxLevels && host_lc[l]; l++) { st.n_wide += host_lc[l]; st.wide_levels = l + 1; st.direct_hint_lc[l] = host_lc[l]; }
+    st.direct_hint_n = n; st.direct_hint_levels = st.wide_levels; st.direct_hint_leaf = S.leaf_max;
+    st.counts_pending = false;
     for (uint32_t l = st.wide_levels; l-- > 0;)
-        hipLaunchKernelGGL(k_dw_emit, dim3((host_lc[l] + 31u) / 32u), dim3(256), 0, stream, E, start[l], host_lc[l]);
+        hipLaunchKernelGGL(k_dw_emit, dim3(std::min<uint32_t>((host_lc[l] + 31u) / 32u, 65536u)), dim3(256), 0, stream, E, (const uint32_t *)lc, l);
     HIP_TRY(hipGetLastError());
     return true;
 }

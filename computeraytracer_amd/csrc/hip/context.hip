@@ -34,6 +34,8 @@ struct crt_context {
     struct TailTune { int decided = -1; uint32_t calls = 0, samples[3] = {0, 0, 0}; float best[3] = {3.4e38f, 3.4e38f, 3.4e38f}; } tune;
     uint32_t slot_next = 0;
     hipEvent_t ev_build[2] = {nullptr, nullptr};
+    bool build_time_pending = false;      // an enqueue-only crt_bvh_build: its device time is read at the next blocking call
+    DeviceBuffer refit_cost;              // two floats: sum of node areas, area of the root (crt_bvh_refit)
     std::string error;
     crt_config cfg{};
     bool configured = false, have_scene = false, have_bvh = false;
@@ -170,7 +172,30 @@ int harvest_slot(crt_context *ctx, crt_context::TimingSlot &sl, bool block) {
 
 // Blocking: every dispatch issued so far has its time read (older slot first, so last_render_ms is the newest) and,
 // with crt_set_kernel_timing on, the k_wf_extend events are summed.
+int finish_build(crt_context *ctx) {
+    // an enqueue-only build (crt_bvh_build with build_ms == NULL): its time, its node counts, and whether the launch plan
+    // was deep enough
+    if (ctx->build_time_pending) {
+        CTX_HIP(hipEventSynchronize(ctx->ev_build[1]));
+        float ms = 0.0f;
+        CTX_HIP(hipEventElapsedTime(&ms, ctx->ev_build[0], ctx->ev_build[1]));
+        ctx->last_build_ms = ms;
+        ctx->build_time_pending = false;
+    }
+    if (ctx->build.counts_pending) {
+        bool overflow = false; std::string err;
+        if (!resolve_wide_counts(ctx->build, overflow, err)) return fail(ctx, CRT_ERR_HIP, err);
+        if (overflow) {
+            ctx->have_bvh = false;
+            return fail(ctx, CRT_ERR_INVALID, "the enqueue-only crt_bvh_build planned for a shallower tree than this frame's primitives needed (parts of the scene were "
+                                              "left out of the BVH and of every image rendered since); call crt_bvh_build again");
+        }
+    }
+    return CRT_OK;
+}
+
 int finish_timing(crt_context *ctx) {
+    { int rc = finish_build(ctx); if (rc) return rc; }
     for (uint32_t k = 0; k < 2; k++) {
         int rc = harvest_slot(ctx, ctx->slot[(ctx->slot_next + k) & 1u], true);
         if (rc) return rc;
@@ -289,7 +314,7 @@ void crt_destroy(crt_context *ctx) {
     if (!ctx) return;
     if (hipSetDevice(ctx->device) == hipSuccess) {
         hipError_t e = hipStreamSynchronize(ctx->stream); (void)e;
-        DeviceBuffer *all[] = {&ctx->spheres, &ctx->quads, &ctx->tris, &ctx->tris_rest, &ctx->materials, &ctx->tex0, &ctx->tex_fp, &ctx->tex_table, &ctx->dbg_boxes, &ctx->dbg_scan, &ctx->accum, &ctx->hit_ids, &ctx->stats};
+        DeviceBuffer *all[] = {&ctx->spheres, &ctx->quads, &ctx->tris, &ctx->tris_rest, &ctx->materials, &ctx->tex0, &ctx->tex_fp, &ctx->tex_table, &ctx->dbg_boxes, &ctx->dbg_scan, &ctx->accum, &ctx->hit_ids, &ctx->stats, &ctx->refit_cost};
         for (DeviceBuffer *b : all) release(*b);
         free_build_state(ctx->build);
         free_wavefront(ctx->wf);
@@ -361,7 +386,9 @@ int crt_scene_upload(crt_context *ctx, const crt_scene_desc *s) {
     if ((ctx->ext & CRT_EXT_TEXTURE_INDEX) && !tex_index_ok)
         return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload: a material's textureIndex is past the texture array (CRT_EXT_TEXTURE_INDEX is set)");
     CTX_HIP(hipStreamSynchronize(ctx->stream));
+    if ((rc = finish_build(ctx))) { ctx->error.clear(); }      // a pending table of the old scene: nobody needs its verdict any more
     ctx->have_scene = false; ctx->have_bvh = false; ctx->animated = false; ctx->n_dbg_boxes = 0;
+    ctx->build.direct_hint_levels = 0; ctx->build.direct_hint_n = 0; ctx->build.records_fresh = false;
     if ((rc = upload(ctx, ctx->spheres, s->spheres, (size_t)s->n_spheres * sizeof(crt_sphere)))) return rc;
     if ((rc = upload(ctx, ctx->quads, s->quads, (size_t)s->n_quads * sizeof(crt_quad)))) return rc;
     if ((rc = upload(ctx, ctx->tris, s->tris, (size_t)s->n_tris * sizeof(crt_tri)))) return rc;
@@ -413,7 +440,12 @@ int crt_extensions_set(crt_context *ctx, uint32_t ext_flags) {
 int crt_bvh_build(crt_context *ctx, uint32_t flags, float *build_ms) {
     int rc = bind(ctx); if (rc) return rc;
     if (!ctx->have_scene) return fail(ctx, CRT_ERR_INVALID, "crt_bvh_build: no scene uploaded");
-    rc = finish_timing(ctx); if (rc) return rc;
+    // build_ms == NULL with CRT_BVH_WIDE_DIRECT: the call may only enqueue (abi.h); everything else waits as before
+    const bool may_skip_waits = build_ms == nullptr && (flags & CRT_BVH_WIDE_DIRECT) != 0 && !ctx->wf.time_kernels;
+    if (may_skip_waits) {
+        if ((rc = finish_build(ctx))) return rc;      // the previous build's table (it finished long ago: a dispatch ran after it)
+        for (uint32_t k = 0; k < 2; k++) if ((rc = harvest_slot(ctx, ctx->slot[(ctx->slot_next + k) & 1u], false))) return rc;
+    } else { rc = finish_timing(ctx); if (rc) return rc; }
     BuildInput in{(const crt_sphere *)ctx->spheres.ptr, ctx->n_spheres, (const crt_quad *)ctx->quads.ptr, ctx->n_quads,
                   (const crt_tri *)ctx->tris.ptr, ctx->n_tris};
     std::string err;
@@ -422,16 +454,55 @@ int crt_bvh_build(crt_context *ctx, uint32_t flags, float *build_ms) {
     if (const char *e = getenv("CRT_BVH_CT")) ctx->build.c_trav = (float)atof(e);
     hipEvent_t e0 = ctx->ev_build[0], e1 = ctx->ev_build[1];      // owned by the context: no event is created (or leaked) per build
     ctx->have_bvh = false;
+    ctx->build.async_request = may_skip_waits;
     CTX_HIP(hipEventRecord(e0, ctx->stream));
     bool ok = build_bvh(ctx->stream, in, flags, ctx->build, err);
     CTX_HIP(hipEventRecord(e1, ctx->stream));
+    ctx->build.async_request = false;
     if (!ok) return fail(ctx, CRT_ERR_HIP, "crt_bvh_build: " + err);
+    ctx->have_bvh = true;
+    if (ctx->build.counts_pending) {      // the build only enqueued: time and counts at the next blocking call
+        ctx->build_time_pending = true;
+        return CRT_OK;
+    }
     CTX_HIP(hipEventSynchronize(e1));
     float ms = 0.0f;
     CTX_HIP(hipEventElapsedTime(&ms, e0, e1));
     ctx->last_build_ms = ms;
+    ctx->build_time_pending = false;
     if (build_ms) *build_ms = ms;
+    return CRT_OK;
+}
+
+int crt_bvh_refit(crt_context *ctx, float *cost) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!ctx->have_scene) return fail(ctx, CRT_ERR_INVALID, "crt_bvh_refit: no scene uploaded");
+    if ((rc = finish_build(ctx))) return rc;
+    if (ctx->build.n_wide == 0) return fail(ctx, CRT_ERR_INVALID, "crt_bvh_refit: no 8-wide tree (build with CRT_BVH_WIDE or CRT_BVH_WIDE_DIRECT first)");
+    if (ctx->build.n_prims != ctx->n_spheres + ctx->n_quads + ctx->n_tris) return fail(ctx, CRT_ERR_INVALID, "crt_bvh_refit: the scene changed size since the build");
+    BuildInput in{(const crt_sphere *)ctx->spheres.ptr, ctx->n_spheres, (const crt_quad *)ctx->quads.ptr, ctx->n_quads,
+                  (const crt_tri *)ctx->tris.ptr, ctx->n_tris};
+    if (cost && (rc = alloc(ctx, ctx->refit_cost, 256))) return rc;
+    std::string err;
+    ctx->have_bvh = false;
+    if (!refit_wide(ctx->stream, in, ctx->build, cost ? (float *)ctx->refit_cost.ptr : nullptr, err)) return fail(ctx, CRT_ERR_HIP, "crt_bvh_refit: " + err);
+    ctx->build.pairs_valid = false;      // the pair tree (megakernel tracer, crt_bvh_read) still has the old boxes
     ctx->have_bvh = true;
+    if (cost) {
+        float h[2] = {0.0f, 0.0f};
+        CTX_HIP(hipMemcpyAsync(h, ctx->refit_cost.ptr, 8, hipMemcpyDeviceToHost, ctx->stream));
+        CTX_HIP(hipStreamSynchronize(ctx->stream));
+        *cost = h[1] > 0.0f ? h[0] / h[1] : 0.0f;
+    }
+    return CRT_OK;
+}
+
+int crt_poll(crt_context *ctx, int *done) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!done) return fail(ctx, CRT_ERR_INVALID, "crt_poll: null output");
+    const hipError_t q = hipStreamQuery(ctx->stream);
+    if (q != hipSuccess && q != hipErrorNotReady) return fail(ctx, CRT_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+    *done = q == hipSuccess ? 1 : 0;
     return CRT_OK;
 }
 
@@ -440,6 +511,7 @@ int crt_tris_update(crt_context *ctx, const crt_tri *tris, uint32_t first, uint3
     if (!ctx->have_scene) return fail(ctx, CRT_ERR_INVALID, "crt_tris_update: no scene uploaded");
     if (!tris || (uint64_t)first + count > ctx->n_tris) return fail(ctx, CRT_ERR_INVALID, "crt_tris_update: range outside the uploaded triangles");
     CTX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->build.records_fresh = false;
     CTX_HIP(hipMemcpy((crt_tri *)ctx->tris.ptr + first, tris, (size_t)count * sizeof(crt_tri), hipMemcpyDefault));
     // after crt_tris_animate the rest pose is a second copy: the update replaces the triangles there too, so the next
     // crt_tris_animate displaces the NEW vertices instead of silently restoring the old ones
@@ -483,7 +555,8 @@ int crt_tris_animate(crt_context *ctx, float frame, float amplitude) {
         ctx->animated = true;
     }
     std::string err;
-    if (!animate_tris(ctx->stream, ctx->n_tris, (const crt_tri *)ctx->tris_rest.ptr, (crt_tri *)ctx->tris.ptr, frame, amplitude, err))
+    if (!animate_tris(ctx->stream, ctx->n_tris, (const crt_tri *)ctx->tris_rest.ptr, (crt_tri *)ctx->tris.ptr, frame, amplitude,
+                      (ctx->n_spheres == 0 && ctx->n_quads == 0) ? &ctx->build : nullptr, err))
         return fail(ctx, CRT_ERR_HIP, "crt_tris_animate: " + err);
     ctx->have_bvh = false;
     return CRT_OK;
@@ -776,6 +849,7 @@ int crt_bvh_wide_read(crt_context *ctx, void *nodes, uint32_t *n_nodes, uint32_t
     int rc = bind(ctx); if (rc) return rc;
     if (!ctx->have_bvh) return fail(ctx, CRT_ERR_INVALID, "crt_bvh_wide_read: no BVH built");
     if (!n_nodes) return fail(ctx, CRT_ERR_INVALID, "crt_bvh_wide_read: null n_nodes");
+    if ((rc = finish_build(ctx))) return rc;
     *n_nodes = ctx->build.n_wide;
     if (n_levels) *n_levels = ctx->build.wide_levels;
     CTX_HIP(hipStreamSynchronize(ctx->stream));

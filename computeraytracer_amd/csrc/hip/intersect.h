@@ -166,15 +166,23 @@ CRT_DEV void test_leaf(const DeviceScene &sc, V3 o, V3 d, uint32_t first, uint32
     uint32_t kind = count_kind >> 28, n = count_kind & 0x0FFFFFFFu;
     if (COUNT) cnt.prims += n;
     if (kind == CRT_ID_KIND_TRI) {
-        for (uint32_t i = 0; i < n; i++) {
+        // Two triangles per trip, both records requested before either is tested: a leaf step waits for one memory round
+        // trip per PAIR instead of one per triangle (the traversal kernels are bound by such dependent waits, not by
+        // arithmetic).  The asm statements keep the compiler from sinking a load behind a test's branch.
+        for (uint32_t i = 0; i < n; i += 2) {
             const float4 *p = sc.tri_pack + 3 * (size_t)(first + i);
-            float4 a = p[0], b = p[1], c = p[2];
-            // all 48 bytes are requested together: left alone the compiler sinks the load of v0 behind the determinant test,
-            // a second dependent round trip in every leaf step (the line is in L1 by then, the wave waits all the same)
-            asm volatile("" :: "v"(a.x), "v"(a.y), "v"(a.z));
+            const bool two = i + 1 < n;
+            const float4 a = p[0], b = p[1], c = p[2];
+            float4 a1 = a, b1 = b, c1 = c;
+            if (two) { a1 = p[3]; b1 = p[4]; c1 = p[5]; }
+            asm volatile("" :: "v"(a.x), "v"(a.y), "v"(a.z), "v"(a1.x), "v"(a1.y), "v"(a1.z), "v"(c1.y));
             float t, beta, gamma, invDet;
             if (tri_t(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, beta, gamma, invDet)) {
                 uint32_t id = f2u(c.y);
+                if (accept_hit(t, id, best_t, best_id) && (!EXT || !(sc.ext & CRT_EXT_ALPHA_TEST) || tri_alpha_pass(sc, id, beta, gamma, invDet))) { best_t = t; best_id = id; }
+            }
+            if (two && tri_t(o, d, mk3(a1.x, a1.y, a1.z), mk3(a1.w, b1.x, b1.y), mk3(b1.z, b1.w, c1.x), t, beta, gamma, invDet)) {
+                uint32_t id = f2u(c1.y);
                 if (accept_hit(t, id, best_t, best_id) && (!EXT || !(sc.ext & CRT_EXT_ALPHA_TEST) || tri_alpha_pass(sc, id, beta, gamma, invDet))) { best_t = t; best_id = id; }
             }
         }

@@ -380,6 +380,7 @@ __global__ __launch_bounds__(256, CRT_EXTEND_WAVES) void k_wf_extend(DeviceScene
                 if (!busy && i < pool_end) {
                     slot = pool_base + i;
                     float4 o4 = ro[slot], d4 = rd[slot];
+                    asm volatile("" :: "v"(o4.x), "v"(o4.y), "v"(o4.z), "v"(o4.w));      // both halves of the entry in one round trip (the compiler would sink the origin's load behind the dead-pixel test)
                     if (f2u(d4.w) == kDeadPixel) q.hit[slot] = make_uint2(f2u(kInf), kIdMiss);
                     else {
                         lt.begin(mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z));

@@ -77,6 +77,23 @@ int crt_extensions_set(crt_context *ctx, uint32_t ext_flags);
  * build over the uploaded primitives.  flags: CRT_BVH_*.  build_ms (optional)
  * receives the device time of the build. */
 int crt_bvh_build(crt_context *ctx, uint32_t flags, float *build_ms);
+/* With build_ms == NULL and CRT_BVH_WIDE_DIRECT the call only ENQUEUES whenever it rebuilds the scene the previous direct
+ * build of this context saw (same primitive count): crt_tris_animate -> crt_bvh_build -> crt_dispatch is then one
+ * stream of launches and the host never waits.  Such a build plans its per-level launches from the previous build's
+ * depth plus two; its device time appears in crt_stats.last_build_ms after the next crt_sync.  A tree that turns out
+ * deeper than planned (the scene's shape changed abruptly between two frames) is reported by the next blocking call
+ * (crt_sync, crt_stats_read, crt_image_read ...) as CRT_ERR_INVALID: the images rendered since lack parts of the
+ * scene and the BVH has to be built again (that build counts its levels the slow way). */
+
+/* Config 5, cheaper variant (SURVEY.md 8(b), row "BVH": crt_bvh_refit/rebuild): recomputes the boxes of the existing
+ * 8-wide tree bottom-up from the primitives as they are now, keeping topology and primitive order; enqueue-only when
+ * cost == NULL.  No counterpart in the reference (it builds once).  Images are the same bits as after a rebuild
+ * (closest hits do not depend on the tree); what degrades as the geometry moves away from the pose the tree was built
+ * for is traversal cost: *cost (optional; makes the call wait) receives sum over nodes of area(node) / area(root), the
+ * figure to compare with the one right after a build when deciding to rebuild.  Needs a tree built with CRT_BVH_WIDE or
+ * CRT_BVH_WIDE_DIRECT; afterwards the pair BVH (megakernel tracer, crt_bvh_read) is stale and refused until the next
+ * build. */
+int crt_bvh_refit(crt_context *ctx, float *cost);
 
 /* Config 5 (per-frame rebuild): overwrite the triangle vertices in place from
  * device-resident or host memory, then call crt_bvh_build again.  No
@@ -134,6 +151,9 @@ int crt_rays_query_noalloc(crt_context *ctx, const crt_ray *rays_dev, uint32_t n
 
 /* Replaces waitForFences(renderFence) (vk_engine.cpp:1377). */
 int crt_sync(crt_context *ctx);
+/* Non-blocking form of the same question (vkGetFenceStatus; the reference only ever blocks): *done = 1 when everything
+ * enqueued on the context so far has finished, 0 while the GPU is still working. */
+int crt_poll(crt_context *ctx, int *done);
 
 /* Replaces the present pass's read of the storage image (vk_engine.cpp:1448-1458):
  * copies the raw accumulation image (RGBA32F, xyz = running sum, w = iteration,

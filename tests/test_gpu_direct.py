@@ -235,3 +235,197 @@ def test_mode_is_measured_and_then_kept(golden_dir):
         assert c.stats().rays == cnt.rays
     finally:
         c.close()
+
+
+# ---- round 3: enqueue-only rebuilds, crt_bvh_refit, crt_poll, config 5 at its full size ----------------------------
+def _animated_reference(scene, tris, p, w, h, accum):
+    moved = abi.HostScene(tris=tris, materials=scene.materials, textures=scene.textures, params=scene.params, name="animated")
+    return orc.render(moved, [p], w, h, flags=orc.TRAVERSE_FAST, accum=accum)
+
+
+def test_enqueue_only_rebuild_matches_the_oracle(ctx):
+    """crt_bvh_build(build_ms = NULL) after a first CRT_BVH_WIDE_DIRECT build only enqueues (launch plan from the previous
+    build's depth): three animated frames, every one against the oracle on the triangles read back; the build's time and
+    node counts arrive with the next blocking call."""
+    w, h = 128, 80
+    scene = abi.builtin_scene("grid:10", w, h)
+    ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+    ctx.upload(scene)
+    ctx.animate(0.0, 0.35)
+    ctx.build(DIRECT)                        # counts its levels: the hint for the frames below
+    _, levels0 = ctx.bvh_wide()
+    seeds = abi.frame_seeds(0, 4)
+    accum = np.zeros((h, w, 4), np.float32)
+    for frame in (1, 2, 3):
+        ctx.animate(float(frame), 0.35)
+        assert ctx.build(DIRECT, wait=False) is None
+        p = scene.params_for(1, seeds[frame - 1])
+        ctx.render(p, 1, np.float32([seeds[frame - 1]]))
+        ctx.sync()
+        assert ctx.stats().last_build_ms > 0.0
+        wide, levels = ctx.bvh_wide()
+        assert len(wide) > 0 and abs(levels - levels0) <= 2
+        tris = ctx.tris_read()
+        ref_img, ref_ids, _ = _animated_reference(scene, tris, p, w, h, accum.copy())
+        assert np.array_equal(ctx.hit_ids(), ref_ids)
+        assert np.array_equal(ctx.image().view(np.uint32), ref_img.view(np.uint32)), f"frame {frame}"
+        accum = ref_img
+    _, sid, qid, tid = ctx.bvh()
+    wide, levels = ctx.bvh_wide()
+    moved = abi.HostScene(tris=ctx.tris_read(), materials=scene.materials, params=scene.params)
+    _check_wide(wide, levels, moved, sid, qid, tid)
+
+
+def test_enqueue_only_rebuild_does_not_wait_for_the_gpu(ctx):
+    """No clock in this test: right after animate + build(wait=False) + dispatch of a 1.16 M-triangle scene have returned,
+    the GPU is still busy with them (crt_poll says so); a build that waited would have drained the stream first."""
+    w, h = 1920, 1080
+    scene = abi.builtin_scene("grid:34", w, h)
+    ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+    ctx.upload(scene)
+    ctx.animate(0.0, 0.35)
+    ctx.build(DIRECT)
+    ctx.sync()
+    assert ctx.poll()
+    seeds = abi.frame_seeds(0, 8)
+    busy = 0
+    for frame in range(1, 7):
+        ctx.animate(float(frame), 0.35)
+        ctx.build(DIRECT, wait=False)
+        busy += 0 if ctx.poll() else 1                   # the build's ~60 launches were just enqueued
+        ctx.dispatch(scene.params_for(frame, seeds[frame - 1]))
+    assert busy >= 5, busy
+    assert not ctx.poll()
+    ctx.sync()
+    assert ctx.poll()
+    assert (ctx.hit_ids() != abi.ID_MISS).mean() > 0.2
+
+
+def test_enqueue_only_rebuild_reports_a_tree_deeper_than_planned(ctx, monkeypatch):
+    """The launch plan comes from the previous build (depth + 2).  When the tree needs more levels than planned (forced here
+    with the CRT_DW_PLAN_SLACK test hook: plan two levels FEWER than the last build had) nothing faults: the parts that
+    would have needed another level are left out, the next blocking call reports it, the context refuses to render until
+    the BVH is built again, and that build (which counts its levels the slow way) is correct."""
+    w, h = 64, 64
+    scene = abi.builtin_scene("grid:4", w, h)          # 16,000 triangles
+    ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+    ctx.upload(scene)
+    ctx.build(DIRECT)
+    _, levels0 = ctx.bvh_wide()
+    assert levels0 >= 4
+    seeds = abi.frame_seeds(0, 1)
+    p = scene.params_for(1, seeds[0])
+    monkeypatch.setenv("CRT_DW_PLAN_SLACK", "-2")
+    ctx.build(DIRECT, wait=False)
+    ctx.render(p, 1, seeds)                             # renders a scene with holes; no fault
+    with pytest.raises(abi.CrtError, match="crt_bvh_build again"):
+        ctx.sync()
+    with pytest.raises(abi.CrtError):
+        ctx.render(p, 1, seeds)
+    monkeypatch.delenv("CRT_DW_PLAN_SLACK")
+    ctx.build(DIRECT, wait=False)                       # no usable hint after an overflow: this one waits and counts
+    _, levels1 = ctx.bvh_wide()
+    assert levels1 == levels0
+    ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+    ctx.render(p, 1, seeds); ctx.sync()
+    ref_img, ref_ids, _ = orc.render(scene, [p], w, h, flags=orc.TRAVERSE_FAST)
+    assert np.array_equal(ctx.hit_ids(), ref_ids) and np.array_equal(ctx.image().view(np.uint32), ref_img.view(np.uint32))
+    ctx.build(DIRECT, wait=False)                       # ... and the next one is enqueue-only again
+    ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+    ctx.render(p, 1, seeds); ctx.sync()
+    assert np.array_equal(ctx.image().view(np.uint32), ref_img.view(np.uint32))
+
+
+@pytest.mark.parametrize("bvh", [DIRECT, abi.BVH_SAH_REFINE | abi.BVH_WIDE, abi.BVH_LBVH | abi.BVH_WIDE], ids=["direct", "sah-wide", "lbvh-wide"])
+def test_refit_only_animation_matches_the_oracle(ctx, bvh):
+    """crt_bvh_refit: build once, then three animated frames with refits only.  Results do not depend on the
+    tree, so images and IDs must be the oracle's on the triangles read back; the reported cost grows as the geometry
+    leaves the pose the tree was built for; the refitted boxes contain what is beneath them (_check_wide)."""
+    w, h = 128, 80
+    scene = abi.builtin_scene("grid:10", w, h)
+    ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+    ctx.upload(scene)
+    ctx.build(bvh)
+    cost0 = ctx.refit(want_cost=True)
+    assert cost0 > 1.0
+    seeds = abi.frame_seeds(0, 4)
+    accum = np.zeros((h, w, 4), np.float32)
+    costs = []
+    for frame in (1, 2, 3):
+        ctx.animate(float(frame), 0.35 * frame)
+        if frame == 2:
+            assert ctx.refit() is None                   # enqueue-only form
+        else:
+            costs.append(ctx.refit(want_cost=True))
+        p = scene.params_for(1, seeds[frame - 1])
+        ctx.render(p, 1, np.float32([seeds[frame - 1]])); ctx.sync()
+        tris = ctx.tris_read()
+        ref_img, ref_ids, _ = _animated_reference(scene, tris, p, w, h, accum.copy())
+        assert np.array_equal(ctx.hit_ids(), ref_ids), f"frame {frame}"
+        assert np.array_equal(ctx.image().view(np.uint32), ref_img.view(np.uint32)), f"frame {frame}"
+        accum = ref_img
+    assert all(c > 1.0 for c in costs)
+    _, sid, qid, tid = ctx.bvh()
+    wide, levels = ctx.bvh_wide()
+    moved = abi.HostScene(tris=ctx.tris_read(), materials=scene.materials, params=scene.params)
+    _check_wide(wide, levels, moved, sid, qid, tid)
+    rays = _query_rays(moved, 3000, 5)
+    ref = orc.hit_rays(moved, rays, flags=orc.TRAVERSE_BRUTE)
+    got = ctx.rays_query(rays, abi.QUERY_CLOSEST)
+    assert np.array_equal(got["id"], ref["id"])
+
+
+def test_refit_mixed_scene_and_errors(ctx, golden_dir):
+    """Spheres + triangles (monkey with its ground sphere): tris_update moves the mesh, refit follows; refit without an
+    8-wide tree and the megakernel after a refit are errors."""
+    w, h = 96, 60
+    scene = abi.builtin_scene("monkey", w, h, golden_dir)
+    ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+    ctx.upload(scene)
+    ctx.build(abi.BVH_SAH_REFINE)
+    with pytest.raises(abi.CrtError, match="8-wide"):
+        ctx.refit()
+    ctx.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE)
+    tris = scene.tris.copy()
+    for f in ("v0", "v1", "v2"):
+        v = tris[f].copy(); v[:, 0] += 0.4; v[:, 1] *= 1.2; tris[f] = v
+    ctx.tris_update(tris)
+    ctx.refit()
+    seeds = abi.frame_seeds(0, 2)
+    ps = [scene.params_for(i + 1, seeds[i]) for i in range(2)]
+    ctx.render(ps[0], 1, seeds); ctx.sync()
+    moved = abi.HostScene(spheres=scene.spheres, tris=tris, materials=scene.materials, textures=scene.textures, params=scene.params)
+    ref_img, ref_ids, _ = orc.render(moved, ps, w, h, flags=orc.TRAVERSE_FAST)
+    assert np.array_equal(ctx.hit_ids(), ref_ids) and np.array_equal(ctx.image().view(np.uint32), ref_img.view(np.uint32))
+    ctx.configure(w, h, tracer=abi.TRACER_MEGAKERNEL)
+    with pytest.raises(abi.CrtError):
+        ctx.render(ps[0], 1, seeds)
+
+
+def test_config5_full_size_direct_vs_collapsed_lbvh():
+    """Config 5 at its real size (10 M triangles, 1080p), one animated frame: CRT_BVH_WIDE_DIRECT and CRT_BVH_LBVH |
+    CRT_BVH_WIDE trees give bit-identical images and IDs, with the per-bounce kernels and with the path kernel (the oracle
+    needs minutes at this size; tree independence is the size-independent property)."""
+    w, h = 1920, 1080
+    scene = abi.builtin_scene("grid10m", w, h)
+    seeds = abi.frame_seeds(0, 1)
+    p = scene.params_for(1, seeds[0])
+    out = {}
+    for bvh in (DIRECT, abi.BVH_LBVH | abi.BVH_WIDE):
+        for mode in (abi.FLAG_PER_BOUNCE_KERNELS, abi.FLAG_PATH_KERNEL):
+            c = abi.Context(0)
+            try:
+                c.configure(w, h, tracer=abi.TRACER_WAVEFRONT, flags=mode)
+                c.upload(scene)
+                c.animate(3.0, 0.35)
+                c.build(bvh)
+                c.dispatch(p); c.sync()
+                out[(bvh, mode)] = (c.image(), c.hit_ids(), c.stats().rays)
+            finally:
+                c.close()
+    first = out[(DIRECT, abi.FLAG_PER_BOUNCE_KERNELS)]
+    assert (first[1] != abi.ID_MISS).mean() > 0.3
+    for k, v in out.items():
+        assert np.array_equal(v[1], first[1]), k
+        assert np.array_equal(v[0].view(np.uint32), first[0].view(np.uint32)), k
+        assert v[2] == first[2], k

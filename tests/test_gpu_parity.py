@@ -783,22 +783,22 @@ def test_deep_sah_tree_is_measured(ctx, monkeypatch):
 
 def test_dispatch_does_not_wait_for_the_gpu(ctx):
     # crt_dispatch is asynchronous (abi.h): a burst of dispatches is enqueued without waiting for each one to finish.
-    # Same image as the blocking sequence; last_render_ms is the time of the LAST dispatch once synced.
-    import time
+    # No clock here (a wall-time bound turns red on a loaded host): right after two 4K dispatches have been
+    # enqueued the stream is still busy (crt_poll), which a blocking call could not leave behind.  Same image as the
+    # blocking sequence; last_render_ms is the time of the LAST dispatch once synced.
     w, h = 3840, 2160
     scene = abi.builtin_scene("corne", w, h)
     ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
     ctx.upload(scene); ctx.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE)
     ps, seeds = _params(scene, 6)
     ctx.dispatch(ps[0]); ctx.sync()
-    one = ctx.stats().last_render_ms
-    t0 = time.perf_counter()
+    assert ctx.poll()
     for p in ps[1:3]:
         ctx.dispatch(p)                          # two dispatches fit the two timing slots: neither call waits
-    enqueue_ms = (time.perf_counter() - t0) * 1e3
+    assert not ctx.poll()                        # several milliseconds of GPU work were enqueued microseconds ago
     ctx.sync()
+    assert ctx.poll()
     assert ctx.stats().last_render_ms > 0
-    assert enqueue_ms < 0.6 * one, (enqueue_ms, one)   # a blocking second call would wait for the first: >= one dispatch's device time
     for p in ps[3:]:
         ctx.dispatch(p)
     ctx.sync()

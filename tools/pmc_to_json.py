@@ -4,7 +4,9 @@
 usage: tools/pmc_to_json.py gpurun_out/pmcN > profiles/rNN_pmc.json
 HBM traffic per launch follows MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are KiB from separate
 passes; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so fetch bytes = 2 * FETCH_SIZE * 1024."""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from computeraytracer_amd import abi      # code_rev(): which kernel sources these counters belong to
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(set)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
@@ -22,4 +24,4 @@ for k in sorted(agg):
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
         d["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
     out[k] = d
-json.dump({"source": sys.argv[1], "kernels": out}, sys.stdout, indent=1)
+json.dump({"source": sys.argv[1], "code_rev": abi.code_rev(), "kernels": out}, sys.stdout, indent=1)
