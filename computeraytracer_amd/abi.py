@@ -98,6 +98,7 @@ def _load():
         "crt_bvh_build": (i32, [vp, u32, P(f32)]),
         "crt_bvh_refit": (i32, [vp, P(f32)]),
         "crt_poll": (i32, [vp, P(i32)]),
+        "crt_retune": (i32, [vp]),
         "crt_tris_update": (i32, [vp, vp, u32, u32]),
         "crt_tris_animate": (i32, [vp, f32, f32]),
         "crt_tris_read": (i32, [vp, vp, u32, u32]),
@@ -365,6 +366,9 @@ class Context:
         c = C.c_float()
         self._check(lib.crt_bvh_refit(self._h, C.byref(c)), "crt_bvh_refit")
         return c.value
+
+    def retune(self):
+        self._check(lib.crt_retune(self._h), "crt_retune")
 
     def poll(self):
         """crt_poll: True when everything enqueued so far has finished."""

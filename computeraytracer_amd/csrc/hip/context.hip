@@ -27,8 +27,8 @@ struct crt_context {
     // launches wait for the longest RAY of every bounce, the tail kernel for the longest PATH, which wins where some rays
     // are very long (10 M-triangle grid seen at grazing angles: 3.1 instead of 4.2 ms a frame) and loses where all
     // are short (cirno 1080p: 1.6 instead of 1.0 ms).  Same image either way, so the context measures: the first
-    // dispatches alternate, two by two, and after three timed samples of each the faster mode stays until the scene or
-    // the configuration changes.  CRT_WF_TAIL_BOUNCE=n fixes the mode (n < 0: never, else the first bounce of the tail kernel).
+    // dispatches take the forms in turn, and after two timed samples of each (six dispatches at most) the fastest stays until the scene or
+    // the configuration changes, or crt_retune asks for a new measurement.  CRT_WF_TAIL_BOUNCE=n fixes the mode (n < 0: never, else the first bounce of the tail kernel).
     // Modes: 0 = a kernel pair per bounce, 1 = one lane per path (k_wf_tail), 2 = the persistent path kernel (k_wf_path; only
     // over an 8-wide tree with no extension set).
     struct TailTune { int decided = -1; uint32_t calls = 0, samples[3] = {0, 0, 0}; float best[3] = {3.4e38f, 3.4e38f, 3.4e38f}; } tune;
@@ -163,7 +163,7 @@ int harvest_slot(crt_context *ctx, crt_context::TimingSlot &sl, bool block) {
         t.samples[sl.tune_mode]++;
         const int n_modes = sl.tune_modes;
         bool done = true;
-        for (int m = 0; m < n_modes; m++) done = done && t.samples[m] >= 3;
+        for (int m = 0; m < n_modes; m++) done = done && t.samples[m] >= 2;      // two samples of each form: six measured dispatches at most
         if (done) { int b = 0; for (int m = 1; m < n_modes; m++) if (t.best[m] < t.best[b]) b = m; t.decided = b; }
     }
     sl.tune_mode = -1;
@@ -249,7 +249,14 @@ void pick_tail(crt_context *ctx, crt_context::TimingSlot *sl, double paths, uint
     if (env_bounce != -100) { ctx->wf.tail_bounce = env_bounce < 0 ? -1 : env_bounce; ctx->wf.tail_persist = env_persist; return; }
     crt_context::TailTune &t = ctx->tune;
     if (t.decided >= 0) { set_mode(t.decided < n_modes ? t.decided : 1); return; }
-    const int mode = (int)((t.calls / 2u) % (uint32_t)n_modes);
+    if (t.calls >= 2u * (uint32_t)n_modes) {
+        // every form has had its two dispatches; until their times are read (one or two calls from now) render with the
+        // best form measured so far instead of alternating on: an interactive engine sees six dispatches of jitter, not twenty
+        int b = 0; for (int m = 1; m < n_modes; m++) if (t.best[m] < t.best[b]) b = m;
+        set_mode(b);
+        return;
+    }
+    const int mode = (int)(t.calls % (uint32_t)n_modes);
     t.calls++;
     set_mode(mode);
     sl->tune_mode = mode; sl->tune_modes = n_modes; sl->tune_scale = (float)iters;
@@ -497,6 +504,12 @@ int crt_bvh_refit(crt_context *ctx, float *cost) {
     return CRT_OK;
 }
 
+int crt_retune(crt_context *ctx) {
+    if (!ctx) return CRT_ERR_INVALID;
+    ctx->tune = crt_context::TailTune();
+    return CRT_OK;
+}
+
 int crt_poll(crt_context *ctx, int *done) {
     int rc = bind(ctx); if (rc) return rc;
     if (!done) return fail(ctx, CRT_ERR_INVALID, "crt_poll: null output");
@@ -638,6 +651,19 @@ int crt_rays_query_noalloc(crt_context *ctx, const crt_ray *rays_dev, uint32_t n
     if ((uintptr_t)rays_dev % 16 != 0 || (uintptr_t)hits_dev % 8 != 0) return fail(ctx, CRT_ERR_INVALID, "crt_rays_query_noalloc: rays must be 16-byte and hits 8-byte aligned");
     // the kernels dereference both pointers: host memory here would be a GPU memory fault, not an error code
     const void *ptrs[2] = {rays_dev, hits_dev};
+    const size_t need[2] = {(size_t)n_rays * sizeof(crt_ray), (size_t)n_rays * sizeof(crt_ray_hit)};
+    for (int k = 0; k < 2; k++) {
+        // ... and the allocation behind each pointer must hold n_rays records from there on (a query, allocates nothing)
+        hipDeviceptr_t base = nullptr; size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptrs[k]) != hipSuccess) {
+            hipError_t e = hipGetLastError(); (void)e;
+            return fail(ctx, CRT_ERR_INVALID, "crt_rays_query_noalloc: rays and hits must be device memory");
+        }
+        const size_t off = (size_t)((const char *)ptrs[k] - (const char *)base);
+        if (off > size || size - off < need[k])
+            return fail(ctx, CRT_ERR_INVALID, k == 0 ? "crt_rays_query_noalloc: the rays allocation holds fewer than n_rays rays from rays_dev on"
+                                                     : "crt_rays_query_noalloc: the hits allocation holds fewer than n_rays hit records from hits_dev on");
+    }
     for (const void *p : ptrs) {
         hipPointerAttribute_t attr{};
         if (hipPointerGetAttributes(&attr, p) != hipSuccess || (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)) {

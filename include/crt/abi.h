@@ -151,6 +151,13 @@ int crt_rays_query_noalloc(crt_context *ctx, const crt_ray *rays_dev, uint32_t n
 
 /* Replaces waitForFences(renderFence) (vk_engine.cpp:1377). */
 int crt_sync(crt_context *ctx);
+/* Small batches (one sample of a frame of up to ~4 M pixels) can be traced by three kernel forms whose ranking depends on
+ * scene and view (types.h: CRT_FLAG_PER_BOUNCE_KERNELS / CRT_FLAG_PATH_KERNEL / CRT_FLAG_PATH_KERNEL_PERSISTENT fix one).
+ * Without such a flag the context measures: its first dispatches after crt_configure / crt_scene_upload take the forms
+ * in turn (two timed samples each: six dispatches at most) and the fastest stays.  crt_retune starts that measurement
+ * again, e.g. after the camera moved to a view with very different ray lengths.  Images do not depend on the form.
+ * No counterpart in the reference (one shader). */
+int crt_retune(crt_context *ctx);
 /* Non-blocking form of the same question (vkGetFenceStatus; the reference only ever blocks): *done = 1 when everything
  * enqueued on the context so far has finished, 0 while the GPU is still working. */
 int crt_poll(crt_context *ctx, int *done);

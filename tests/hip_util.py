@@ -13,6 +13,7 @@ class Hip:
         self.lib.hipFree.argtypes = [C.c_void_p]
         self.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.lib.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        self.lib.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
 
     def malloc(self, n):
         p = C.c_void_p()
@@ -27,6 +28,11 @@ class Hip:
 
     def d2h(self, a, src):
         assert self.lib.hipMemcpy(a.ctypes.data_as(C.c_void_p), C.c_void_p(src), a.nbytes, 2) == 0
+
+    def mem_free(self):
+        f, t = C.c_size_t(), C.c_size_t()
+        assert self.lib.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
 
     def memset(self, p, v, n):
         assert self.lib.hipMemset(C.c_void_p(p), v, n) == 0

@@ -229,6 +229,8 @@ def test_mode_is_measured_and_then_kept(golden_dir):
         ps = [scene.params_for(i + 1, seeds[i]) for i in range(16)]
         for i in range(16):
             c.dispatch(ps[i])
+            if i == 9:
+                c.retune()                       # crt_retune: measure again (six more dispatches in turn), same images
         c.sync()
         ref_img, ref_ids, cnt = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_FAST)
         assert np.array_equal(c.hit_ids(), ref_ids) and np.array_equal(c.image().view(np.uint32), ref_img.view(np.uint32))

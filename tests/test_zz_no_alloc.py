@@ -57,6 +57,29 @@ def test_noalloc_query_equals_the_allocating_one(golden_dir, bvh):
                         assert np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32))
                     else:
                         assert np.array_equal(got["id"] != abi.ID_MISS, want["id"] != abi.ID_MISS)
+            # the headline property: a series of calls leaves the device's free memory where it was
+            rays = _rays(scene, 50_000, 7)
+            hip.h2d(d_rays, rays)
+            ctx.sync()
+            free0 = hip.mem_free()
+            for k in range(6):
+                ctx.rays_query_noalloc(d_rays, 50_000 - 1000 * k, abi.QUERY_CLOSEST if k % 2 else abi.QUERY_ANY, d_hits)
+            assert hip.mem_free() == free0                    # while the calls are still in flight ...
+            ctx.sync()
+            assert hip.mem_free() == free0                    # ... and after
+            # buffers shorter than n_rays records are refused instead of faulting on the GPU
+            small_r, small_h = hip.malloc(1000 * 32), hip.malloc(1000 * 8)
+            try:
+                with pytest.raises(abi.CrtError, match="fewer than n_rays rays"):
+                    ctx.rays_query_noalloc(small_r, 1001, abi.QUERY_CLOSEST, d_hits)
+                with pytest.raises(abi.CrtError, match="fewer than n_rays hit"):
+                    ctx.rays_query_noalloc(d_rays, 1001, abi.QUERY_CLOSEST, small_h)
+                with pytest.raises(abi.CrtError, match="fewer than n_rays rays"):
+                    ctx.rays_query_noalloc(small_r + 32 * 10, 991, abi.QUERY_CLOSEST, d_hits)       # an interior pointer: counted from there
+                hip.h2d(small_r, rays[:1000])
+                ctx.rays_query_noalloc(small_r, 1000, abi.QUERY_CLOSEST, small_h); ctx.sync()        # exactly full is fine
+            finally:
+                hip.free(small_r); hip.free(small_h)
             # errors: too many rays, host memory, null, bad mode; zero rays is a no-op
             with pytest.raises(abi.CrtError, match="131072"):
                 ctx.rays_query_noalloc(d_rays, n_max + 1, abi.QUERY_CLOSEST, d_hits)
