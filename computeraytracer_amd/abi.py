@@ -99,6 +99,7 @@ def _load():
         "crt_bvh_refit": (i32, [vp, P(f32)]),
         "crt_poll": (i32, [vp, P(i32)]),
         "crt_retune": (i32, [vp]),
+        "crt_debug_sort_u64": (i32, [vp, vp, u32, u32, u32]),
         "crt_tris_update": (i32, [vp, vp, u32, u32]),
         "crt_tris_animate": (i32, [vp, f32, f32]),
         "crt_tris_read": (i32, [vp, vp, u32, u32]),
@@ -366,6 +367,11 @@ class Context:
         c = C.c_float()
         self._check(lib.crt_bvh_refit(self._h, C.byref(c)), "crt_bvh_refit")
         return c.value
+
+    def debug_sort_u64(self, keys, bit_lo, bit_hi):
+        k = np.ascontiguousarray(keys, dtype=np.uint64).copy()
+        self._check(lib.crt_debug_sort_u64(self._h, _ptr(k), len(k), bit_lo, bit_hi), "crt_debug_sort_u64")
+        return k
 
     def retune(self):
         self._check(lib.crt_retune(self._h), "crt_retune")

@@ -71,13 +71,18 @@ bool measure_pair_depths(hipStream_t stream, BuildState &st, std::string &err);
 bool build_wide(hipStream_t stream, BuildState &st, std::string &err);
 struct PackOut;
 bool build_wide_direct(hipStream_t stream, const BuildInput &in, BuildState &st, const uint64_t *keys, uint32_t idx_bits, const uint32_t *rank_sphere,
-                       const uint32_t *rank_quad, const PackOut &out, std::string &err);
+                       const uint32_t *rank_quad, const PackOut &out, const uint32_t *sort_error, std::string &err);
 // After an enqueue-only direct build: waits for its level table and takes node count, depth and the next build's hint
 // from it.  overflow: the tree was deeper than the launches planned for (parts were dropped: the BVH is not usable).
 bool resolve_wide_counts(BuildState &st, bool &overflow, std::string &err);
 // Boxes of the existing 8-wide tree recomputed bottom-up from the primitives as they are now (crt_bvh_refit); topology,
 // leaf contents and primitive order stay.  cost_dev (optional): receives sum over nodes of area(node), and area(root) in [1].
 bool refit_wide(hipStream_t stream, const BuildInput &in, BuildState &st, float *cost_dev, std::string &err);
+// bvh_sort.hip: LSD radix sort of 64-bit keys over bits [bit_lo, bit_hi), keys only; enqueue-only.  *sorted = the buffer that
+// holds the result; *error_word = a device word that is non-zero afterwards if a look-back wait gave up (never seen).
+size_t radix_sort_scratch_bytes(uint32_t n);
+bool radix_sort_keys_u64(hipStream_t stream, uint64_t *keys_a, uint64_t *keys_b, uint32_t n, uint32_t bit_lo, uint32_t bit_hi, void *scratch,
+                         const uint64_t **sorted, const uint32_t **error_word, std::string &err);
 bool animate_tris(hipStream_t stream, uint32_t n, const crt_tri *rest, crt_tri *out, float frame, float amplitude, BuildState *st, std::string &err);
 void free_build_state(BuildState &st);
 

@@ -637,7 +637,15 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     else HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, dkeys, dvals, n, 0, key_bits, stream));
     HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t *)st.flag_a.ptr, (uint32_t *)st.rank_a.ptr, 0u, n,
                                     rocprim::plus<uint32_t>(), stream));
-    if (!ensure(st.temp, std::max(sort_bytes, scan_bytes), err)) return false;
+    // CRT_BVH_SORT=onesweep: the keys-only sorts of more than a million keys (the per-frame rebuilds) go through the
+    // hand-written sort of bvh_sort.hip instead of rocPRIM's.  Measured at 10 M keys, 39 key bits (profiles/r03_build_stats_10m_direct.md):
+    // 83.7 us per digit pass + 108 us for the histograms against rocPRIM's 63.6 us per pass + 53 us of offsets + 56 us of
+    // fills, i.e. 2.64 instead of 2.49 ms per config-5 frame: rocPRIM stays the default ("if it cannot
+    // beat rocPRIM, keep rocPRIM and write the measured reason").  The sort is correct (tests/test_gpu_sort.py) and stays
+    // in the tree as the starting point: its ranking step serialises sixteen LDS round trips per wave and tile.
+    static const bool env_own_sort = [] { const char *e = getenv("CRT_BVH_SORT"); return e && std::string(e) == "onesweep"; }();
+    const bool own_sort = idx_bits != 0 && n > (1u << 20) && env_own_sort;
+    if (!ensure(st.temp, std::max(std::max(sort_bytes, scan_bytes), own_sort ? radix_sort_scratch_bytes(n) : (size_t)0), err)) return false;
 
     // the animation pass already left records, centroids and centroid bounds of exactly these triangles (animate_tris)
     const bool have_records = direct && st.records_fresh && in.n_tris == n;
@@ -664,9 +672,15 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
                        direct ? (const float4 *)nullptr : (const float4 *)st.phi.ptr, (const uint32_t *)st.scene_bounds.ptr, (uint64_t *)st.keys.ptr, (uint32_t *)st.vals.ptr);
     HIP_TRY(hipGetLastError());
     size_t tb = st.temp.bytes;
-    if (idx_bits) HIP_TRY(rocprim::radix_sort_keys(st.temp.ptr, tb, dkeys, n, idx_bits, idx_bits + key_bits, stream));
-    else HIP_TRY(rocprim::radix_sort_pairs(st.temp.ptr, tb, dkeys, dvals, n, 0, key_bits, stream));
-    const uint64_t *keys = dkeys.current(); const uint32_t *vals = dvals.current();
+    const uint64_t *keys = nullptr; const uint32_t *sort_error = nullptr;
+    if (own_sort) {
+        if (!radix_sort_keys_u64(stream, (uint64_t *)st.keys.ptr, (uint64_t *)st.keys_alt.ptr, n, idx_bits, idx_bits + key_bits, st.temp.ptr, &keys, &sort_error, err)) return false;
+    } else {
+        if (idx_bits) HIP_TRY(rocprim::radix_sort_keys(st.temp.ptr, tb, dkeys, n, idx_bits, idx_bits + key_bits, stream));
+        else HIP_TRY(rocprim::radix_sort_pairs(st.temp.ptr, tb, dkeys, dvals, n, 0, key_bits, stream));
+        keys = dkeys.current();
+    }
+    const uint32_t *vals = dvals.current();
 
     if (direct) {
         const uint32_t idx_mask = (uint32_t)((1ull << idx_bits) - 1ull);
@@ -682,7 +696,7 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
                      (uint32_t *)st.quad_ids.ptr, (uint32_t *)st.tri_ids.ptr};
         st.sorted_vals = nullptr;
         return build_wide_direct(stream, in, st, keys, idx_bits, mixed ? (const uint32_t *)st.rank_a.ptr : nullptr,
-                                 mixed ? (const uint32_t *)st.rank_b.ptr : nullptr, pout, err);
+                                 mixed ? (const uint32_t *)st.rank_b.ptr : nullptr, pout, sort_error, err);
     }
 
     // SAH refinement: the Karras hierarchy only clusters; bvh_sah.hip rebuilds the topology and reorders the primitives

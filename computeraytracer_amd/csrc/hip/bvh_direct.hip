@@ -187,8 +187,9 @@ __global__ __launch_bounds__(256) void k_dw_split(DwSplit A, uint32_t level, con
     }
 }
 
-__global__ void k_dw_init(uint32_t *level_count, uint32_t n_levels, uint2 *q0, uint32_t n) {
-    for (uint32_t i = threadIdx.x; i <= n_levels + 1u; i += blockDim.x) level_count[i] = i == 0 ? 1u : 0u;      // [n_levels + 1] = the overflow word
+__global__ void k_dw_init(uint32_t *level_count, uint32_t n_levels, uint2 *q0, uint32_t n, const uint32_t *sort_error) {
+    // [n_levels + 1] = the status word: bit 0 = tree deeper than planned (k_dw_split), bit 1 = the key sort gave up
+    for (uint32_t i = threadIdx.x; i <= n_levels + 1u; i += blockDim.x) level_count[i] = i == 0 ? 1u : (i == n_levels + 1u && sort_error && *sort_error) ? 2u : 0u;
     if (threadIdx.x == 0) q0[0] = make_uint2(0u, n);
 }
 
@@ -259,7 +260,7 @@ bool resolve_wide_counts(BuildState &st, bool &overflow, std::string &err) {
     HIP_TRY(hipEventSynchronize(st.ev_counts));
     st.counts_pending = false;
     const uint32_t *h = st.host_lc;
-    overflow = h[kWideMaxLevels + 2] != 0u;
+    overflow = h[kWideMaxLevels + 2] != 0u;      // bit 0: deeper than planned; bit 1: the key sort gave up (as unusable, reported the same way)
     st.n_wide = 0; st.wide_levels = 0;
     for (uint32_t l = 0; l <= kWideMaxLevels && h[l]; l++) { st.n_wide += h[l]; st.wide_levels = l + 1; st.direct_hint_lc[l] = h[l]; }
     for (uint32_t l = st.wide_levels; l < kWideMaxLevels + 3; l++) st.direct_hint_lc[l] = 0;
@@ -268,7 +269,7 @@ bool resolve_wide_counts(BuildState &st, bool &overflow, std::string &err) {
 }
 
 bool build_wide_direct(hipStream_t stream, const BuildInput &in, BuildState &st, const uint64_t *keys, uint32_t idx_bits, const uint32_t *rank_sphere,
-                       const uint32_t *rank_quad, const PackOut &out, std::string &err) {
+                       const uint32_t *rank_quad, const PackOut &out, const uint32_t *sort_error, std::string &err) {
     const uint32_t n = st.n_prims;
     st.n_wide = 0; st.wide_levels = 0;
     if (n == 0) return true;
@@ -288,7 +289,7 @@ bool build_wide_direct(hipStream_t stream, const BuildInput &in, BuildState &st,
     DwSplit S{keys, idx_bits, single_kind ? env_leaf : 1u, lc, (float4 *)st.wide.ptr, (uint32_t *)links};
     DwEmit E{keys, (uint32_t)((1ull << idx_bits) - 1ull), n, in, rank_sphere, rank_quad, (const float4 *)st.tri_shade.ptr, out,
              (float4 *)st.wide.ptr, links, (float4 *)st.nlo.ptr};
-    hipLaunchKernelGGL(k_dw_init, dim3(1), dim3(128), 0, stream, lc, kWideMaxLevels + 1, (uint2 *)st.wide_queue[0].ptr, n);
+    hipLaunchKernelGGL(k_dw_init, dim3(1), dim3(128), 0, stream, lc, kWideMaxLevels + 1, (uint2 *)st.wide_queue[0].ptr, n, sort_error);
     const uint32_t grid = std::min<uint32_t>(2048u, (st.n_pairs + 255u) / 256u);
     // Enqueue-only: a rebuild of the scene the previous direct build saw (same primitive count and leaf size) replays
     // that build's launch plan two levels deeper, nothing is read back before the launches: crt_tris_animate ->
@@ -327,6 +328,7 @@ bool build_wide_direct(hipStream_t stream, const BuildInput &in, BuildState &st,
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(host_lc, lc, (kWideMaxLevels + 3) * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        if (host_lc[kWideMaxLevels + 2] & 2u) { err = "the key sort's look-back wait gave up"; return false; }
         if (host_lc[level] == 0) break;
         if (level >= kWideMaxLevels) { err = "wide BVH deeper than 64 levels"; return false; }
     }

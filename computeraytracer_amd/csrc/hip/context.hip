@@ -504,6 +504,28 @@ int crt_bvh_refit(crt_context *ctx, float *cost) {
     return CRT_OK;
 }
 
+int crt_debug_sort_u64(crt_context *ctx, uint64_t *keys, uint32_t n, uint32_t bit_lo, uint32_t bit_hi) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (n && !keys) return fail(ctx, CRT_ERR_INVALID, "crt_debug_sort_u64: null keys");
+    if (bit_lo > bit_hi || bit_hi > 64) return fail(ctx, CRT_ERR_INVALID, "crt_debug_sort_u64: bit range");
+    if (n == 0) return CRT_OK;
+    DeviceBuffer a, b, scratch;
+    std::string err;
+    rc = alloc(ctx, a, (size_t)n * 8); if (!rc) rc = alloc(ctx, b, (size_t)n * 8); if (!rc) rc = alloc(ctx, scratch, radix_sort_scratch_bytes(n));
+    const uint64_t *sorted = nullptr; const uint32_t *ew = nullptr;
+    uint32_t flag = 0;
+    bool ok = false;
+    if (!rc && hipMemcpy(a.ptr, keys, (size_t)n * 8, hipMemcpyHostToDevice) == hipSuccess &&
+        radix_sort_keys_u64(ctx->stream, (uint64_t *)a.ptr, (uint64_t *)b.ptr, n, bit_lo, bit_hi, scratch.ptr, &sorted, &ew, err) &&
+        hipStreamSynchronize(ctx->stream) == hipSuccess && hipMemcpy(keys, sorted, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+        (!ew || hipMemcpy(&flag, ew, 4, hipMemcpyDeviceToHost) == hipSuccess)) ok = true;
+    release(a); release(b); release(scratch);
+    if (rc) return rc;
+    if (!ok) return fail(ctx, CRT_ERR_HIP, "crt_debug_sort_u64: " + (err.empty() ? std::string("HIP call failed") : err));
+    if (flag) return fail(ctx, CRT_ERR_HIP, "crt_debug_sort_u64: a look-back wait gave up");
+    return CRT_OK;
+}
+
 int crt_retune(crt_context *ctx) {
     if (!ctx) return CRT_ERR_INVALID;
     ctx->tune = crt_context::TailTune();

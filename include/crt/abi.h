@@ -235,6 +235,11 @@ int crt_bvh_read(crt_context *ctx, crt_bvh_node *nodes, uint32_t *n_nodes,
  * Build-only diagnostic, no counterpart in the reference. */
 int crt_bvh_wide_read(crt_context *ctx, void *nodes, uint32_t *n_nodes, uint32_t *n_levels);
 
+/* Build-only diagnostic: sorts n host keys on the device over bits [bit_lo, bit_hi) with the build's own radix sort
+ * (bvh_sort.hip; stable, so keys that agree on those bits keep their order) and copies them back.  For the sort's unit
+ * test; no counterpart in the reference (std::sort inside its builder, bounding_volume_hierarchy.cpp:26-61). */
+int crt_debug_sort_u64(crt_context *ctx, uint64_t *keys, uint32_t n, uint32_t bit_lo, uint32_t bit_hi);
+
 /* The AABB-outline debug view (camera.shouldRenderAABB, compute.comp:427-436) draws the boxes of the REFERENCE's
  * BVHNode array (set 0 binding 2, vk_engine.cpp:1203), which the device-side build does not produce.  A caller that
  * wants the view supplies that array (64-byte nodes, T1 layout; only the boxes are read); it belongs to the current

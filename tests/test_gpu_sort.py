@@ -1,0 +1,39 @@
+"""The build's own radix sort (bvh_sort.hip, crt_debug_sort_u64) against numpy on Morton-shaped keys: code << idx_bits |
+index with long runs of equal codes, sorted over the code's bits only; stable, so keys with equal codes keep their order
+(= a stable numpy sort by the masked key).  Sizes cross the 4096-key tile, the single-tile case and several thousand
+tiles."""
+import numpy as np
+import pytest
+
+from computeraytracer_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def _keys(n, idx_bits, code_bits, seed, runs):
+    rs = np.random.RandomState(seed)
+    code = rs.randint(0, 1 << min(code_bits, 62), size=n, dtype=np.int64).astype(np.uint64)
+    if runs:        # long runs of equal codes (flat terrain: many centroids in one cell)
+        code = code[rs.randint(0, max(1, n // runs), size=n)]
+    if code_bits < 64 - idx_bits:
+        code &= np.uint64((1 << code_bits) - 1)
+    return (code << np.uint64(idx_bits)) | np.arange(n, dtype=np.uint64)[rs.permutation(n)]
+
+
+@pytest.mark.parametrize("n,idx_bits,code_bits,runs", [(1, 1, 39, 0), (2, 1, 8, 0), (4096, 12, 39, 0), (4097, 13, 39, 50), (100_000, 17, 30, 0),
+                                                       (1_000_003, 20, 39, 1000), (3_000_000, 22, 13, 0), (10_000_000, 24, 39, 7)])
+def test_radix_sort_matches_a_stable_numpy_sort(n, idx_bits, code_bits, runs):
+    keys = _keys(n, idx_bits, code_bits, n % 97, runs)
+    with abi.Context(0) as ctx:
+        got = ctx.debug_sort_u64(keys, idx_bits, idx_bits + code_bits)
+    order = np.argsort(keys >> np.uint64(idx_bits), kind="stable")
+    assert np.array_equal(got, keys[order])
+
+
+def test_radix_sort_full_width_and_empty_range():
+    rs = np.random.RandomState(5)
+    keys = rs.randint(0, 1 << 62, size=70_000, dtype=np.int64).astype(np.uint64) * np.uint64(3)
+    with abi.Context(0) as ctx:
+        assert np.array_equal(ctx.debug_sort_u64(keys, 0, 64), np.sort(keys))
+        assert np.array_equal(ctx.debug_sort_u64(keys, 5, 5), keys)          # no bits: nothing moves
+        assert np.array_equal(ctx.debug_sort_u64(keys, 60, 64), keys[np.argsort(keys >> np.uint64(60), kind="stable")])
