@@ -379,7 +379,12 @@ def main():
 
     phase.set("scene_upload")
     ctx = abi.Context(local_rank)
-    ctx.configure(W, H, tracer=tracer, band_rank=rank, band_world=world)
+    # The per-frame-rebuild workload dispatches one small batch per frame, for which the context would otherwise measure
+    # its three kernel forms over the first dispatches and keep the fastest (which one wins can differ from run to run
+    # when two are close: ADVICE r2).  The benchmark fixes the form that measurement has always picked on this workload
+    # (one lane per path, k_wf_tail), so that runs are reproducible; CRT_BENCH_TUNE=1 leaves the choice to the context.
+    cfg_flags = abi.FLAG_PATH_KERNEL if args.workload == "grid10m_1080p" and os.environ.get("CRT_BENCH_TUNE", "") != "1" else 0
+    ctx.configure(W, H, tracer=tracer, band_rank=rank, band_world=world, flags=cfg_flags)
     ctx.upload(scene)
     bvh_flags = {"lbvh": abi.BVH_LBVH, "sah": abi.BVH_SAH_REFINE, "collapse": abi.BVH_LEAF_COLLAPSE,
                  "lbvh-wide": abi.BVH_LBVH | abi.BVH_WIDE, "sah-wide": abi.BVH_SAH_REFINE | abi.BVH_WIDE, "direct": abi.BVH_WIDE_DIRECT}[args.bvh]
@@ -544,6 +549,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "scene": scene_name, "width": W, "height": H, "spp_per_step": spp,
                        "tris": int(len(scene.tris)), "spheres": int(len(scene.spheres)), "quads": int(len(scene.quads)),
+                       "kernel_form": {0: "per-bounce (batches) / measured (single samples)", abi.FLAG_PATH_KERNEL: "path kernel, one lane per path (fixed)"}[cfg_flags],
                        "tracer": args.tracer, "bvh": args.bvh + ("+refit per frame" if rebuild and args.refit else ""), "rng": "ref-hash", "parallelism": f"tile{world}" if world > 1 else "single",
                        "bvh_build_ms": round(build_ms, 4), "gather_ms": None if gather_ms is None else round(gather_ms, 3),
                        "gather": gather_path, "gather_check": gather_check,
