@@ -112,6 +112,7 @@ def _load():
         "crt_hit_ids_read": (i32, [vp, vp, C.c_size_t]),
         "crt_image_device_ptr": (i32, [vp, P(vp), P(C.c_size_t)]),
         "crt_image_copy_to_device": (i32, [vp, vp, C.c_size_t]),
+        "crt_image_export_fd": (i32, [vp, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "crt_band_rows": (u32, [u32, u32, u32, vp]),
         "crt_comm_unique_id": (i32, [vp]),
         "crt_comm_init": (i32, [vp, vp, u32, u32]),
@@ -435,6 +436,13 @@ class Context:
 
     def image_copy_to_device(self, device_ptr, n_bytes):
         self._check(lib.crt_image_copy_to_device(self._h, C.c_void_p(device_ptr), n_bytes), "crt_image_copy_to_device")
+
+    def image_export_fd(self, want_fd=True):
+        """crt_image_export_fd: enqueues the copy of the band buffer into the exportable allocation; returns (fd or None,
+        image_bytes, alloc_bytes).  The caller owns the descriptor (os.close it, or hand it to an importer that takes it over)."""
+        fd, nb, ab = C.c_int(-1), C.c_size_t(), C.c_size_t()
+        self._check(lib.crt_image_export_fd(self._h, C.byref(fd) if want_fd else None, C.byref(nb), C.byref(ab)), "crt_image_export_fd")
+        return (fd.value if want_fd else None), nb.value, ab.value
 
     def comm_init(self, comm_id, rank, world):
         """crt_comm_init: comm_id = the 128 bytes rank 0 got from comm_unique_id()."""

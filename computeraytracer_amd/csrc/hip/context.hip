@@ -49,6 +49,9 @@ struct crt_context {
     BuildState build;
     // image
     DeviceBuffer accum, hit_ids, stats;
+    // crt_image_export_fd: a copy of the band buffer in memory that other APIs can import (HIP virtual memory management:
+    // a physical allocation that exports as a dma-buf file descriptor, mapped into this process at `va`)
+    struct ExportImage { hipMemGenericAllocationHandle_t handle{}; void *va = nullptr; size_t alloc_bytes = 0, image_bytes = 0; bool live = false; } exported;
     uint32_t grid_w = 0, grid_h = 0, n_local_bands = 0, local_rows = 0;
     WavefrontState wf;
     GatherState gather;
@@ -102,6 +105,14 @@ int alloc(crt_context *ctx, DeviceBuffer &b, size_t bytes) {
 }
 
 void release(DeviceBuffer &b) { if (b.ptr) { hipError_t e = hipFree(b.ptr); (void)e; } b.ptr = nullptr; b.bytes = 0; }
+
+void release_export(crt_context *ctx) {
+    crt_context::ExportImage &x = ctx->exported;
+    if (x.live) {
+        hipError_t e = hipMemUnmap(x.va, x.alloc_bytes); e = hipMemAddressFree(x.va, x.alloc_bytes); e = hipMemRelease(x.handle); (void)e;
+    }
+    x = crt_context::ExportImage();
+}
 
 int upload(crt_context *ctx, DeviceBuffer &b, const void *src, size_t bytes) {
     int rc = alloc(ctx, b, bytes);
@@ -323,6 +334,7 @@ void crt_destroy(crt_context *ctx) {
         hipError_t e = hipStreamSynchronize(ctx->stream); (void)e;
         DeviceBuffer *all[] = {&ctx->spheres, &ctx->quads, &ctx->tris, &ctx->tris_rest, &ctx->materials, &ctx->tex0, &ctx->tex_fp, &ctx->tex_table, &ctx->dbg_boxes, &ctx->dbg_scan, &ctx->accum, &ctx->hit_ids, &ctx->stats, &ctx->refit_cost};
         for (DeviceBuffer *b : all) release(*b);
+        release_export(ctx);
         free_build_state(ctx->build);
         free_wavefront(ctx->wf);
         comm_destroy(ctx->gather);
@@ -770,6 +782,55 @@ int crt_image_copy_to_device(crt_context *ctx, void *dst_device, size_t n_bytes)
         return fail(ctx, CRT_ERR_INVALID, "crt_image_copy_to_device: destination must hold exactly the band buffer");
     CTX_HIP(hipMemcpyAsync(dst_device, ctx->accum.ptr, n_bytes, hipMemcpyDeviceToDevice, ctx->stream));
     CTX_HIP(hipStreamSynchronize(ctx->stream));
+    return CRT_OK;
+}
+
+int crt_image_export_fd(crt_context *ctx, int *fd, size_t *image_bytes, size_t *alloc_bytes) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!ctx->configured) return fail(ctx, CRT_ERR_INVALID, "crt_image_export_fd: not configured");
+    const size_t need = (size_t)ctx->local_rows * ctx->cfg.width * 16;
+    crt_context::ExportImage &x = ctx->exported;
+    if (x.live && x.image_bytes != need) {      // a different frame size: importers hold their own reference to the old memory
+        CTX_HIP(hipStreamSynchronize(ctx->stream));
+        release_export(ctx);
+    }
+    if (!x.live) {
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.requestedHandleType = hipMemHandleTypePosixFileDescriptor;
+        prop.location.type = hipMemLocationTypeDevice; prop.location.id = ctx->device;
+        size_t gran = 0;
+        CTX_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+        if (gran == 0) gran = 1u << 21;
+        const size_t bytes = (need + gran - 1) / gran * gran;
+        hipMemGenericAllocationHandle_t h{};
+        CTX_HIP(hipMemCreate(&h, bytes, &prop, 0));
+        void *va = nullptr;
+        hipError_t e = hipMemAddressReserve(&va, bytes, gran, nullptr, 0);
+        if (e == hipSuccess) {
+            e = hipMemMap(va, bytes, 0, h, 0);
+            if (e == hipSuccess) {
+                hipMemAccessDesc acc{};
+                acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+                e = hipMemSetAccess(va, bytes, &acc, 1);
+                if (e != hipSuccess) { hipError_t e2 = hipMemUnmap(va, bytes); (void)e2; }
+            }
+            if (e != hipSuccess) { hipError_t e2 = hipMemAddressFree(va, bytes); (void)e2; }
+        }
+        if (e != hipSuccess) {
+            hipError_t e2 = hipMemRelease(h); (void)e2;
+            return fail(ctx, CRT_ERR_HIP, std::string("crt_image_export_fd: mapping the exportable allocation: ") + hipGetErrorString(e));
+        }
+        x.handle = h; x.va = va; x.alloc_bytes = bytes; x.image_bytes = need; x.live = true;
+    }
+    CTX_HIP(hipMemcpyAsync(x.va, ctx->accum.ptr, need, hipMemcpyDeviceToDevice, ctx->stream));
+    if (fd) {
+        int h = -1;
+        CTX_HIP(hipMemExportToShareableHandle(&h, x.handle, hipMemHandleTypePosixFileDescriptor, 0));
+        *fd = h;
+    }
+    if (image_bytes) *image_bytes = need;
+    if (alloc_bytes) *alloc_bytes = x.alloc_bytes;
     return CRT_OK;
 }
 

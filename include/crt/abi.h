@@ -181,6 +181,17 @@ int crt_image_device_ptr(crt_context *ctx, void **device_ptr, size_t *n_bytes);
 /* Copies the packed band buffer into caller-owned device memory (e.g. a torch
  * tensor that RCCL will gather) and waits for the copy. */
 int crt_image_copy_to_device(crt_context *ctx, void *dst_device, size_t n_bytes);
+/* Device-side hand-over of the frame to another API, in place of the read-back above (the reference has no such step: its
+ * storage image is written and sampled by the same Vulkan device, vk_engine.cpp:1429-1458).  Enqueues a device-to-device
+ * copy of the packed band buffer (the whole image with band_world <= 1) into an allocation of the context that exports as
+ * a dma-buf file descriptor (HIP virtual memory management, hipMemHandleTypePosixFileDescriptor); crt_sync / crt_poll say
+ * when the copy has landed.
+ *   fd           non-NULL: receives a NEW descriptor for that allocation on every call; the caller owns it (Vulkan's
+ *                vkAllocateMemory with VkImportMemoryFdInfoKHR takes it over; otherwise close() it).  Engines import once
+ *                and pass NULL afterwards: the allocation stays the same until the frame size changes;
+ *   image_bytes  rows owned * width * 16;  alloc_bytes = the allocation's size (image_bytes rounded up to the device's
+ *                allocation granularity): the size an importer has to name. */
+int crt_image_export_fd(crt_context *ctx, int *fd, size_t *image_bytes, size_t *alloc_bytes);
 /* ---- multi-GPU gather; the reference is single-GPU (vk_engine.cpp:156-157), so none of these has a
  * counterpart there.  One process per GPU; each renders its bands (crt_config.band_rank / band_world) and the finished
  * frame is assembled with ONE all-gather over RCCL (xGMI) + an un-interleave kernel.  RCCL is bound at run time

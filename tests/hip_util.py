@@ -36,3 +36,38 @@ class Hip:
 
     def memset(self, p, v, n):
         assert self.lib.hipMemset(C.c_void_p(p), v, n) == 0
+
+    # --- importing a dma-buf descriptor the way another API would (tests of crt_image_export_fd) ---
+    class _Loc(C.Structure):
+        _fields_ = [("type", C.c_int), ("id", C.c_int)]
+
+    class _Access(C.Structure):
+        _fields_ = [("type", C.c_int), ("id", C.c_int), ("flags", C.c_int)]
+
+    def import_fd(self, fd, n_bytes, device=0):
+        """hipMemImportFromShareableHandle + reserve + map + access; returns (device address, handle)."""
+        L = self.lib
+        L.hipMemImportFromShareableHandle.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
+        L.hipMemAddressReserve.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t, C.c_void_p, C.c_ulonglong]
+        L.hipMemMap.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_ulonglong]
+        L.hipMemSetAccess.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(self._Access), C.c_size_t]
+        h, va = C.c_void_p(), C.c_void_p()
+        rc = L.hipMemImportFromShareableHandle(C.byref(h), C.c_void_p(fd), 1)
+        assert rc == 0, f"hipMemImportFromShareableHandle: {rc}"
+        rc = L.hipMemAddressReserve(C.byref(va), n_bytes, 0, None, 0)
+        assert rc == 0, f"hipMemAddressReserve: {rc}"
+        rc = L.hipMemMap(va, n_bytes, 0, h, 0)
+        assert rc == 0, f"hipMemMap: {rc}"
+        acc = self._Access(1, device, 3)
+        rc = L.hipMemSetAccess(va, n_bytes, C.byref(acc), 1)
+        assert rc == 0, f"hipMemSetAccess: {rc}"
+        return va.value, h.value
+
+    def release_import(self, va, h, n_bytes):
+        L = self.lib
+        L.hipMemUnmap.argtypes = [C.c_void_p, C.c_size_t]
+        L.hipMemAddressFree.argtypes = [C.c_void_p, C.c_size_t]
+        L.hipMemRelease.argtypes = [C.c_void_p]
+        assert L.hipMemUnmap(C.c_void_p(va), n_bytes) == 0
+        assert L.hipMemAddressFree(C.c_void_p(va), n_bytes) == 0
+        assert L.hipMemRelease(C.c_void_p(h)) == 0
