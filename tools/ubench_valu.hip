@@ -124,6 +124,19 @@ __global__ __launch_bounds__(256) void k_valu(int trips, float seed, float *out)
 #define I_XOR(k) "v_xor_b32 %" #k ", %" #k ", %[w]\n"
 #define I_SUBREV(k) "v_subrev_f32 %" #k ", %[m], %" #k "\n"
 #define I_ADD3(k) "v_add3_u32 %" #k ", %" #k ", %[w], %[w]\n"
+#define I_FMAS(k) "v_fma_f32 %" #k ", s10, %" #k ", %[c]\n"
+#define I_FMAS2(k) "v_fma_f32 %" #k ", s10, %[m], %[c]\n"
+#define I_MULS(k) "v_mul_f32 %" #k ", s10, %" #k "\n"
+#define I_MULLIT(k) "v_mul_f32 %" #k ", 0x3f7fbe77, %" #k "\n"
+#define I_MULINL(k) "v_mul_f32 %" #k ", 1.0, %" #k "\n"
+#define I_ANDLIT(k) "v_and_b32 %" #k ", 0xfffffe00, %" #k "\n"
+#define I_ANDINL(k) "v_and_b32 %" #k ", 63, %" #k "\n"
+#define I_ANDS(k) "v_and_b32 %" #k ", s10, %" #k "\n"
+#define I_FMAINL(k) "v_fma_f32 %" #k ", %" #k ", %[m], 1.0\n"
+#define I_FMAABS(k) "v_fma_f32 %" #k ", |%" #k "|, %[m], -%[c]\n"
+#define I_ADDE64(k) "v_add_f32_e64 %" #k ", %" #k ", %[m]\n"
+#define I_MOVS(k) "v_mov_b32 %" #k ", s10\n"
+#define I_MOVLIT(k) "v_mov_b32 %" #k ", 0x3f7fbe77\n"
 SURVEY_KERNEL(add, R8(I_ADD)) SURVEY_KERNEL(mul, R8(I_MUL)) SURVEY_KERNEL(sub, R8(I_SUB)) SURVEY_KERNEL(max, R8(I_MAX)) SURVEY_KERNEL(min, R8(I_MIN))
 SURVEY_KERNEL(max3, R8(I_MAX3)) SURVEY_KERNEL(med3, R8(I_MED3)) SURVEY_KERNEL(mov, R8(I_MOV)) SURVEY_KERNEL(and_, R8(I_AND)) SURVEY_KERNEL(or_, R8(I_OR))
 SURVEY_KERNEL(lshl, R8(I_LSHL)) SURVEY_KERNEL(addu, R8(I_ADDU)) SURVEY_KERNEL(perm, R8(I_PERM)) SURVEY_KERNEL(andor, R8(I_ANDOR)) SURVEY_KERNEL(or3, R8(I_OR3))
@@ -134,6 +147,10 @@ SURVEY_KERNEL(cndmask64, "s_mov_b64 s[10:11], exec\n" R8(I_CNDMASK64)) SURVEY_KE
 SURVEY_KERNEL(cmpsel32, R8(I_CMPSEL32)) SURVEY_KERNEL(cmpsel64, R8(I_CMPSEL64)) SURVEY_KERNEL(cmpseln, R8(I_CMPSELN))
 SURVEY_KERNEL(cmp1sel8v, "v_cmp_le_f32 vcc, %0, %[m]\n" R8(I_CNDMASKC)) SURVEY_KERNEL(cmp1sel8s, "v_cmp_le_f32_e64 s[10:11], %0, %[m]\n" R8(I_CNDMASK64))
 SURVEY_KERNEL(xor_, R8(I_XOR)) SURVEY_KERNEL(subrev, R8(I_SUBREV)) SURVEY_KERNEL(add3, R8(I_ADD3))
+SURVEY_KERNEL(mullit, R8(I_MULLIT)) SURVEY_KERNEL(mulinl, R8(I_MULINL)) SURVEY_KERNEL(andlit, R8(I_ANDLIT)) SURVEY_KERNEL(andinl, R8(I_ANDINL))
+SURVEY_KERNEL(ands, "s_mov_b32 s10, 0x3f7fbe77\n" R8(I_ANDS)) SURVEY_KERNEL(fmainl, R8(I_FMAINL)) SURVEY_KERNEL(fmaabs, R8(I_FMAABS))
+SURVEY_KERNEL(adde64, R8(I_ADDE64)) SURVEY_KERNEL(movs, "s_mov_b32 s10, 0x3f7fbe77\n" R8(I_MOVS)) SURVEY_KERNEL(movlit, R8(I_MOVLIT))
+SURVEY_KERNEL(fmas, "s_mov_b32 s10, 0x3f7fbe77\n" R8(I_FMAS)) SURVEY_KERNEL(fmas2, "s_mov_b32 s10, 0x3f7fbe77\n" R8(I_FMAS2)) SURVEY_KERNEL(muls, "s_mov_b32 s10, 0x3f7fbe77\n" R8(I_MULS))
 
 typedef void (*survey_fn)(int, float, float *);
 static double run_survey(survey_fn fn, int blocks_per_cu, int n_cu, int trips, float *out, double clock_hz) {
@@ -202,7 +219,10 @@ int main() {
             printf("%-18s %6d %14.4f %14.2f\n", names[kind], w, r, r * 64.0);
         }
     struct { const char *name; survey_fn fn; } sv[] = {
-        {"v_add_f32", k_sv_add}, {"v_mul_f32", k_sv_mul}, {"v_sub_f32", k_sv_sub}, {"v_subrev_f32", k_sv_subrev}, {"v_fma_f32", k_sv_fma}, {"v_fmac_f32", k_sv_fmac},
+        {"v_mul_f32 literal", k_sv_mullit}, {"v_mul_f32 inline 1.0", k_sv_mulinl}, {"v_and_b32 literal", k_sv_andlit}, {"v_and_b32 inline 63", k_sv_andinl}, {"v_and_b32 sgpr (x8/9)", k_sv_ands},
+        {"v_fma_f32 inline 1.0 src2", k_sv_fmainl}, {"v_fma_f32 abs/neg modifiers", k_sv_fmaabs}, {"v_add_f32_e64 (VOP3 encoding)", k_sv_adde64},
+        {"v_mov_b32 sgpr (x8/9)", k_sv_movs}, {"v_mov_b32 literal", k_sv_movlit},
+        {"v_fma_f32 sgpr src0 (x8/9)", k_sv_fmas}, {"v_fma_f32 sgpr src0, vgpr consts (x8/9)", k_sv_fmas2}, {"v_mul_f32 sgpr src0 (x8/9)", k_sv_muls}, {"v_add_f32", k_sv_add}, {"v_mul_f32", k_sv_mul}, {"v_sub_f32", k_sv_sub}, {"v_subrev_f32", k_sv_subrev}, {"v_fma_f32", k_sv_fma}, {"v_fmac_f32", k_sv_fmac},
         {"v_mul_legacy_f32", k_sv_mulleg}, {"v_max_f32", k_sv_max}, {"v_min_f32", k_sv_min}, {"v_max3_f32", k_sv_max3}, {"v_med3_f32", k_sv_med3},
         {"v_mov_b32", k_sv_mov}, {"v_and_b32", k_sv_and_}, {"v_or_b32", k_sv_or_}, {"v_xor_b32", k_sv_xor_}, {"v_lshlrev_b32", k_sv_lshl}, {"v_add_u32", k_sv_addu}, {"v_add3_u32", k_sv_add3},
         {"v_perm_b32", k_sv_perm}, {"v_and_or_b32", k_sv_andor}, {"v_or3_b32", k_sv_or3}, {"v_bfe_u32", k_sv_bfe}, {"v_lshl_or_b32", k_sv_lshlor}, {"v_alignbit_b32", k_sv_alignbit},
