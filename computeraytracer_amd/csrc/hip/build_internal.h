@@ -40,6 +40,8 @@ struct BuildState {
     uint32_t n_wide = 0, wide_levels = 0;
     uint32_t pair_depth = 0;                         // levels of the SAH-refined pair tree (0: not measured, LBVH <= 95)
     bool pairs_valid = false;                        // false after a CRT_BVH_WIDE_DIRECT build: no pair tree, only the 8-wide one
+    bool fuse_dp = false;                            // build_sah should make the wide collapse's table while it builds (set by build_bvh: CRT_BVH_SAH_REFINE | CRT_BVH_WIDE)
+    bool dp_fused = false;                           // ... and did: dp_choice is complete, word 7 of dp_cost row 0 carries the pair tree's height << 21
     bool levels_measured = false;                    // level_hist / dp_depth describe the current pairs (bvh_sah.hip: measure_pair_depths)
     uint32_t level_hist[128] = {};                   // pairs per depth (root = 1)
     // Enqueue-only direct rebuilds (bvh_direct.hip).  A CRT_BVH_WIDE_DIRECT build that may not wait for the GPU launches its
@@ -69,6 +71,8 @@ bool build_sah(hipStream_t stream, const BuildInput &in, BuildState &st, const u
 bool patch_sah_links(hipStream_t stream, BuildState &st, std::string &err);
 bool measure_pair_depths(hipStream_t stream, BuildState &st, std::string &err);
 bool build_wide(hipStream_t stream, BuildState &st, std::string &err);
+bool wide_collapse_greedy();      // CRT_WIDE_GREEDY=1: no table (A/B runs)
+uint32_t pair_depth_limit();      // kMaxPairDepth, or less (CRT_BVH_MAX_PAIR_DEPTH: test hook)
 struct PackOut;
 bool build_wide_direct(hipStream_t stream, const BuildInput &in, BuildState &st, const uint64_t *keys, uint32_t idx_bits, const uint32_t *rank_sphere,
                        const uint32_t *rank_quad, const PackOut &out, const uint32_t *sort_error, std::string &err);

@@ -575,7 +575,7 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     const uint32_t n = in.n_spheres + in.n_quads + in.n_tris;
     st.n_prims = n;
     st.n_pairs = n == 0 ? 0 : (n == 1 ? 1 : n - 1);
-    st.n_wide = 0; st.wide_levels = 0; st.levels_measured = false; st.pair_depth = 0;
+    st.n_wide = 0; st.wide_levels = 0; st.levels_measured = false; st.pair_depth = 0; st.dp_fused = false;
     const bool wide = (flags & CRT_BVH_WIDE) != 0;
     // CRT_BVH_WIDE_DIRECT (bvh_direct.hip): the 8-wide tree straight from the sorted keys; no pair tree and none of its scratch
     const bool direct = (flags & CRT_BVH_WIDE_DIRECT) != 0;
@@ -701,6 +701,7 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
 
     // SAH refinement: the Karras hierarchy only clusters; bvh_sah.hip rebuilds the topology and reorders the primitives
     const bool sah = (flags & CRT_BVH_SAH_REFINE) != 0 && n >= 2;
+    st.fuse_dp = sah && wide && !wide_collapse_greedy() && !getenv("CRT_BVH_DP_LEVELS");      // CRT_BVH_DP_LEVELS=1: the table by separate level launches (A/B)
     const uint32_t *order = vals;
     if (n >= 2) {
         if (!ensure(st.range_lo, (size_t)n * 4, err) || !ensure(st.range_hi, (size_t)n * 4, err)) return false;

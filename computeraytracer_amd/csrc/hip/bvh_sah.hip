@@ -28,6 +28,7 @@
 
 #include "build_internal.h"
 #include "bvh_common.h"
+#include "bvh_dp.h"
 
 namespace crt {
 
@@ -82,6 +83,9 @@ struct SahGroupArgs {
     float4 *pairs;
     uint32_t *perm;            // level 0: final primitive order
     uint32_t max_leaf; float c_isect, c_trav;
+    // fused collapse table (bvh_wide.hip; null: not wanted): eight words per pair (only a group's root row is written: the
+    // next tier reads it), one choice word per pair
+    float *dp_cost; unsigned long long *dp_choice;
 };
 
 struct SahLds {
@@ -93,7 +97,11 @@ struct SahLds {
     uint32_t red[12];                // centroid min, centroid max, box min, box max (encoded)
     uint32_t wave_cnt[kSahWaves];
     uint32_t top, n_small, cursor, best_axis, best_plane, best_nl;
+    float dp[7][kGroup];             // fused collapse table: c(1..7) of the group's pairs
+    uint32_t dp_w[kGroup];           // their eff tables | subtree height << 21
+    uint8_t dp_done[kGroup];
 };
+constexpr bool kSahCanFuseDp = kGroup <= kSahThreads;      // one thread per pair of a group
 
 // work entry: x = a | b << 16 (item range [a, b) of the permutation), y = p | pp << 11 | side << 22 | root << 23
 // (p = first pair owned by the subtree, pp/side = where its descriptor goes: half `side` of pair pp).
@@ -453,6 +461,64 @@ __global__ __launch_bounds__(kSahThreads) void k_sah_group(SahGroupArgs g) {
     }
     __syncthreads();
     if (g.level0) for (uint32_t i = tid; i < m; i += kSahThreads) g.perm[gs + i] = g.vals[gs + L.idx[i]];
+    // ---- the wide collapse's table (bvh_wide.hip: c(n, i), choice words) for the m - 1 pairs this group has just written,
+    // bottom-up inside the workgroup: thread t owns pair pair_base + t and computes it in the round after its in-group
+    // children are done (rounds = height of the group's subtree; two barriers each).  Children outside the group are roots
+    // of the tier below: their rows are in global memory since the previous launch.  As separate level-by-level launches
+    // over the finished tree this took 21 launches of ~4.5 us plus the parent / depth / bucket passes that fed them.
+    // The subtree's height travels with the eff table, so the depth limit of the pair tracers needs no pass of its own.
+    if (kSahCanFuseDp && g.dp_cost != nullptr && m >= 2u) {
+        const uint32_t np = m - 1u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the pairs were written by other threads of this workgroup
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const bool mine = tid < np;
+        float alo[3] = {0.0f, 0.0f, 0.0f}, ahi[3] = {0.0f, 0.0f, 0.0f}, blo[3] = {0.0f, 0.0f, 0.0f}, bhi[3] = {0.0f, 0.0f, 0.0f};
+        uint32_t la = 0, lb = 0, ka = 0, kb = 0;      // k: 0 = costs nothing (leaf, hole), 1 = pair `l` of this group, 2 = root `l` of a group below
+        if (mine) {
+            const float4 *pp = g.pairs + 4 * (size_t)(pair_base + tid);
+            const float4 a0 = pp[0], a1 = pp[1], b0 = pp[2], b1 = pp[3];
+            alo[0] = a0.x; alo[1] = a0.y; alo[2] = a0.z; ahi[0] = a1.x; ahi[1] = a1.y; ahi[2] = a1.z;
+            blo[0] = b0.x; blo[1] = b0.y; blo[2] = b0.z; bhi[0] = b1.x; bhi[1] = b1.y; bhi[2] = b1.z;
+            la = __float_as_uint(a0.w); lb = __float_as_uint(b0.w);
+            const uint32_t ca = __float_as_uint(a1.w), cb = __float_as_uint(b1.w);
+            if (ca == 0u && la != 0u) { if (la >= pair_base && la - pair_base < np) { ka = 1u; la -= pair_base; } else ka = 2u; }
+            if (cb == 0u && lb != 0u) { if (lb >= pair_base && lb - pair_base < np) { kb = 1u; lb -= pair_base; } else kb = 2u; }
+        }
+        if (tid < kGroup) L.dp_done[tid] = 0;
+        __syncthreads();
+        bool done = !mine;
+        for (;;) {
+            const bool go = !done && (ka != 1u || L.dp_done[la] != 0) && (kb != 1u || L.dp_done[lb] != 0);
+            if (go) {
+                float cl[8], cr[8];
+#pragma unroll
+                for (int k = 1; k < 8; k++) {
+                    cl[k] = ka == 1u ? L.dp[k - 1][la] : ka == 2u ? g.dp_cost[8 * (size_t)la + (k - 1)] : 0.0f;
+                    cr[k] = kb == 1u ? L.dp[k - 1][lb] : kb == 2u ? g.dp_cost[8 * (size_t)lb + (k - 1)] : 0.0f;
+                }
+                const uint32_t wa = ka == 1u ? L.dp_w[la] : ka == 2u ? __float_as_uint(g.dp_cost[8 * (size_t)la + 7]) : 0u;
+                const uint32_t wb = kb == 1u ? L.dp_w[lb] : kb == 2u ? __float_as_uint(g.dp_cost[8 * (size_t)lb + 7]) : 0u;
+                float c[8]; uint32_t own; unsigned long long w;
+                dp_combine(alo, ahi, blo, bhi, cl, cr, wa, wb, c, own, w);
+                const uint32_t h = min(1u + max(wa >> 21, wb >> 21), 1023u);
+                const uint32_t word = own | (h << 21);
+#pragma unroll
+                for (int k = 1; k < 8; k++) L.dp[k - 1][tid] = c[k];
+                L.dp_w[tid] = word;
+                g.dp_choice[pair_base + tid] = w;
+                if (tid == 0) {      // the group's root: the row the tier above (or the host, for the height of pair 0) reads
+                    float *row = g.dp_cost + 8 * (size_t)pair_base;
+#pragma unroll
+                    for (int k = 1; k < 8; k++) row[k - 1] = c[k];
+                    row[7] = __uint_as_float(word);
+                }
+            }
+            __syncthreads();
+            if (go) { L.dp_done[tid] = 1; done = true; }
+            if (!__syncthreads_or(go ? 1 : 0)) break;
+        }
+    }
 }
 
 // Leaf links were written as final sorted positions; turn them into slots of the kind's packed array.
@@ -484,6 +550,9 @@ bool build_sah(hipStream_t stream, const BuildInput &in, BuildState &st, const u
     const size_t cap = (size_t)n + 64;          // groups over all tiers (checked below)
     if (!ensure_buf(st.sah_flag, (size_t)n * 4, err) || !ensure_buf(st.sah_ipos[0], (size_t)n * 4, err) || !ensure_buf(st.sah_ipos[1], (size_t)n * 4, err)) return false;
     if (!ensure_buf(st.sah_starts, cap * 4, err) || !ensure_buf(st.sah_desc, cap * 2 * sizeof(float4), err) || !ensure_buf(st.perm, (size_t)n * 4, err)) return false;
+    const bool fuse = st.fuse_dp && kSahCanFuseDp;
+    st.dp_fused = false;
+    if (fuse && (!ensure_buf(st.dp_cost, (size_t)st.n_pairs * 8 * 4, err) || !ensure_buf(st.dp_choice, (size_t)st.n_pairs * 8, err))) return false;
     size_t scan_bytes = 0;
     HIP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, (uint32_t *)st.sah_flag.ptr, (uint32_t *)st.sah_ipos[0].ptr, n, rocprim::plus<uint32_t>(), stream));
     if (!ensure_buf(st.temp, scan_bytes, err)) return false;
@@ -529,10 +598,12 @@ bool build_sah(hipStream_t stream, const BuildInput &in, BuildState &st, const u
         g.desc_out = t + 1 == tiers.size() ? nullptr : desc + 2 * tiers[t].starts_off;
         g.pairs = (float4 *)st.pairs.ptr; g.perm = (uint32_t *)st.perm.ptr;
         g.max_leaf = st.max_leaf < 1u ? 1u : st.max_leaf > 8u ? 8u : st.max_leaf; g.c_isect = st.c_isect; g.c_trav = st.c_trav;
+        g.dp_cost = fuse ? (float *)st.dp_cost.ptr : nullptr; g.dp_choice = fuse ? (unsigned long long *)st.dp_choice.ptr : nullptr;
         hipLaunchKernelGGL(k_sah_group, dim3(g.n_groups), dim3(kSahThreads), 0, stream, g);
     }
     HIP_TRY(hipGetLastError());
     st.sah_tiers = (uint32_t)tiers.size();
+    st.dp_fused = fuse;
     return true;
 }
 
@@ -587,13 +658,19 @@ bool measure_pair_depths(hipStream_t stream, BuildState &st, std::string &err) {
     return true;
 }
 
+uint32_t pair_depth_limit() {
+    uint32_t limit = kMaxPairDepth;
+    if (const char *e = getenv("CRT_BVH_MAX_PAIR_DEPTH")) { const int v = atoi(e); if (v >= 1 && (uint32_t)v < limit) limit = (uint32_t)v; }   // test hook: can only lower it
+    return limit;
+}
+
 bool patch_sah_links(hipStream_t stream, BuildState &st, std::string &err) {
     const uint32_t halves = 2 * st.n_pairs;
     hipLaunchKernelGGL(k_sah_patch_links, dim3((halves + 255) / 256), dim3(256), 0, stream, halves, (float4 *)st.pairs.ptr, (const uint32_t *)st.leaf_link.ptr);
     HIP_TRY(hipGetLastError());
+    if (st.dp_fused) return true;      // the collapse table is done and carries the tree's height: build_wide checks it at its own synchronisation
     if (!measure_pair_depths(stream, st, err)) return false;
-    uint32_t limit = kMaxPairDepth;
-    if (const char *e = getenv("CRT_BVH_MAX_PAIR_DEPTH")) { const int v = atoi(e); if (v >= 1 && (uint32_t)v < limit) limit = (uint32_t)v; }   // test hook: can only lower it
+    const uint32_t limit = pair_depth_limit();
     if (st.pair_depth > limit) {
         err = "SAH-refined tree is " + std::to_string(st.pair_depth) + " levels deep; the pair traversal stacks hold " + std::to_string(limit);
         return false;

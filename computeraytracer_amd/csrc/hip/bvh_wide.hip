@@ -48,6 +48,7 @@
 
 #include "build_internal.h"
 #include "bvh_common.h"
+#include "bvh_dp.h"
 
 namespace crt {
 
@@ -100,39 +101,12 @@ __global__ void k_dp_level(const float4 *pairs, const uint32_t *list, uint32_t f
     float cl[8], cr[8];                                   // index 1 .. 7
 #pragma unroll
     for (int k = 1; k < 8; k++) { cl[k] = a.count == 0u ? cost[8 * (size_t)a.link + (k - 1)] : 0.0f; cr[k] = b.count == 0u ? cost[8 * (size_t)b.link + (k - 1)] : 0.0f; }
-    const unsigned long long eff_l = a.count == 0u ? (unsigned long long)__float_as_uint(cost[8 * (size_t)a.link + 7]) : 0ull;
-    const unsigned long long eff_r = b.count == 0u ? (unsigned long long)__float_as_uint(cost[8 * (size_t)b.link + 7]) : 0ull;
-    float lo[3], hi[3];
+    const uint32_t eff_l = a.count == 0u ? __float_as_uint(cost[8 * (size_t)a.link + 7]) : 0u;
+    const uint32_t eff_r = b.count == 0u ? __float_as_uint(cost[8 * (size_t)b.link + 7]) : 0u;
+    float c[8]; uint32_t own; unsigned long long w;
+    dp_combine(a.lo, a.hi, b.lo, b.hi, cl, cr, eff_l, eff_r, c, own, w);
 #pragma unroll
-    for (int ax = 0; ax < 3; ax++) { lo[ax] = fminf(a.lo[ax], b.lo[ax]); hi[ax] = fmaxf(a.hi[ax], b.hi[ax]); }
-    const float area = half_area3(lo, hi);
-    float dist[9]; uint32_t split[9];
-#pragma unroll
-    for (int j = 2; j <= 8; j++) {
-        float best = 3.402823466e38f; uint32_t bk = 1;
-#pragma unroll
-        for (int k = 1; k < j; k++) {
-            if (k > 7 || j - k > 7) continue;
-            const float v = cl[k] + cr[j - k];
-            if (v < best) { best = v; bk = (uint32_t)k; }
-        }
-        dist[j] = best; split[j] = bk;
-    }
-    float c[8]; uint32_t eff[8];
-    c[1] = area + dist[8]; eff[1] = 1u;
-    if (!(c[1] < 3.402823466e38f)) c[1] = 3.402823466e38f;      // NaN / overflow areas: still a valid (finite) table
-#pragma unroll
-    for (int k = 2; k < 8; k++) {
-        const bool take = dist[k] < c[k - 1];
-        c[k] = take ? dist[k] : c[k - 1];
-        eff[k] = take ? (uint32_t)k : eff[k - 1];
-    }
-    unsigned long long w = (eff_l << 21) | (eff_r << 42);
-    uint32_t own = 0u;
-#pragma unroll
-    for (int j = 2; j <= 8; j++) w |= (unsigned long long)split[j] << (3 * (j - 2));
-#pragma unroll
-    for (int k = 1; k < 8; k++) { own |= eff[k] << (3 * (k - 1)); cost[8 * (size_t)n + (k - 1)] = c[k]; }
+    for (int k = 1; k < 8; k++) cost[8 * (size_t)n + (k - 1)] = c[k];
     cost[8 * (size_t)n + 7] = __uint_as_float(own);
     choice[n] = w;
 }
@@ -401,6 +375,11 @@ static bool ensure_w(DeviceBuffer &b, size_t bytes, std::string &err) {
     return true;
 }
 
+bool wide_collapse_greedy() {
+    static const bool greedy = [] { const char *e = getenv("CRT_WIDE_GREEDY"); return e && atoi(e) != 0; }();
+    return greedy;
+}
+
 bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
     st.n_wide = 0; st.wide_levels = 0;
     if (st.n_pairs == 0) return true;
@@ -414,9 +393,10 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
     uint32_t *lc = (uint32_t *)st.wide_levels_dev.ptr;
     // ---- the table (only when the pairs' depths were measured, i.e. after the SAH refinement: the per-frame LBVH rebuild
     // keeps the cheaper greedy rule): buckets by depth -> one launch per depth, deepest first ------------------------------
-    static const bool greedy = [] { const char *e = getenv("CRT_WIDE_GREEDY"); return e && atoi(e) != 0; }();
+    const bool greedy = wide_collapse_greedy();
     const unsigned long long *choice = nullptr;
-    if (!greedy && st.levels_measured && st.n_pairs > 1) {
+    if (!greedy && st.dp_fused && st.n_pairs > 1) choice = (const unsigned long long *)st.dp_choice.ptr;      // made by k_sah_group
+    else if (!greedy && st.levels_measured && st.n_pairs > 1) {
         const uint32_t np = st.n_pairs;
         if (!ensure_w(st.dp_cost, (size_t)np * 8 * 4, err) || !ensure_w(st.dp_choice, (size_t)np * 8, err) || !ensure_w(st.dp_list, (size_t)np * 4, err)) return false;
         uint32_t *cursor = (uint32_t *)st.dp_hist.ptr + kDpLevels;      // zeroed by measure_pair_depths
@@ -435,6 +415,7 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
                        (uint2 *)st.wide_queue[0].ptr, (uint2 *)st.wide_queue[1].ptr, (float4 *)st.wide.ptr, links);
     const uint32_t grid = std::min<uint32_t>(2048u, (st.n_pairs + 127u) / 128u);
     uint32_t host_lc[kWideMaxLevels + 3];
+    uint32_t root_word = 0; bool height_read = false;
     uint32_t level = 1;      // k_wide_top always does level 0 (one node)
     for (;;) {
         const uint32_t chunk_end = std::min<uint32_t>(level + 8u, kWideMaxLevels);
@@ -444,7 +425,16 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
                                (float4 *)st.wide.ptr, links);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(host_lc, lc, (kWideMaxLevels + 3) * 4, hipMemcpyDeviceToHost, stream));
+        if (st.dp_fused && !height_read) HIP_TRY(hipMemcpyAsync(&root_word, (const float *)st.dp_cost.ptr + 7, 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        if (st.dp_fused && !height_read) {      // the pair tree's height came with the table (bvh_sah.hip): the pair tracers' stacks bound it
+            height_read = true;
+            st.pair_depth = root_word >> 21;
+            if (st.pair_depth > pair_depth_limit()) {
+                err = "SAH-refined tree is " + std::to_string(st.pair_depth) + " levels deep; the pair traversal stacks hold " + std::to_string(pair_depth_limit());
+                return false;
+            }
+        }
         if (host_lc[level] == 0) break;
         if (level >= kWideMaxLevels) { err = "wide BVH deeper than 64 levels"; return false; }
     }

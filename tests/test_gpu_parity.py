@@ -777,8 +777,34 @@ def test_deep_sah_tree_is_measured(ctx, monkeypatch):
         ctx.build(abi.BVH_SAH_REFINE)
     with pytest.raises(abi.CrtError, match="crt_bvh_build has not been called"):
         ctx.dispatch(scene.params)
+    # the 8-wide build learns the height from the collapse table that k_sah_group makes (no depth pass of its own)
+    with pytest.raises(abi.CrtError, match="levels deep"):
+        ctx.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE)
     monkeypatch.delenv("CRT_BVH_MAX_PAIR_DEPTH")
     ctx.build(abi.BVH_SAH_REFINE)
+
+
+@pytest.mark.parametrize("name", ["voxel_city", "cirno", "grid:20", "corne", "nested"])
+def test_collapse_table_fused_into_the_sah_build_equals_the_level_passes(ctx, golden_dir, monkeypatch, name):
+    # CRT_BVH_SAH_REFINE | CRT_BVH_WIDE: every k_sah_group workgroup finishes the collapse table of the subtree it built
+    # (bvh_sah.hip); CRT_BVH_DP_LEVELS=1 makes the same table with one launch per depth over the finished tree
+    # (bvh_wide.hip: k_dp_level).  Same table => the same 8-wide tree, byte for byte, over one, two and three tiers.
+    scene = _nested_scene(100, 64, 48) if name == "nested" else abi.builtin_scene(name, 64, 48, golden_dir)
+    ctx.configure(64, 48, tracer=abi.TRACER_WAVEFRONT)
+    ctx.upload(scene)
+    ctx.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE)
+    fused, levels_f = ctx.bvh_wide()
+    monkeypatch.setenv("CRT_BVH_DP_LEVELS", "1")
+    ctx.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE)
+    monkeypatch.delenv("CRT_BVH_DP_LEVELS")
+    by_level, levels_l = ctx.bvh_wide()
+    assert levels_f == levels_l and len(fused) == len(by_level) and len(fused) > 0
+
+    def canon(nodes):      # node numbers inside a level follow the order of an atomic counter: compare the nodes as a set
+        a = np.asarray(nodes)[:, :16].copy()       # header + the 48 plane bytes
+        a[:, 3] &= 0xFF                            # keep the inner mask, drop the index of the first child
+        return a[np.lexsort(a.T[::-1])]
+    assert np.array_equal(canon(fused), canon(by_level))
 
 
 def test_dispatch_does_not_wait_for_the_gpu(ctx):
