@@ -100,6 +100,7 @@ def _load():
         "crt_poll": (i32, [vp, P(i32)]),
         "crt_retune": (i32, [vp]),
         "crt_debug_sort_u64": (i32, [vp, vp, u32, u32, u32]),
+        "crt_debug_sort_pairs_u64": (i32, [vp, vp, vp, u32, u32, u32]),
         "crt_tris_update": (i32, [vp, vp, u32, u32]),
         "crt_tris_animate": (i32, [vp, f32, f32]),
         "crt_tris_read": (i32, [vp, vp, u32, u32]),
@@ -373,6 +374,12 @@ class Context:
         k = np.ascontiguousarray(keys, dtype=np.uint64).copy()
         self._check(lib.crt_debug_sort_u64(self._h, _ptr(k), len(k), bit_lo, bit_hi), "crt_debug_sort_u64")
         return k
+
+    def debug_sort_pairs_u64(self, keys, vals, bit_lo, bit_hi):
+        k = np.ascontiguousarray(keys, dtype=np.uint64).copy()
+        v = np.ascontiguousarray(vals, dtype=np.uint32).copy()
+        self._check(lib.crt_debug_sort_pairs_u64(self._h, _ptr(k), _ptr(v), len(k), bit_lo, bit_hi), "crt_debug_sort_pairs_u64")
+        return k, v
 
     def retune(self):
         self._check(lib.crt_retune(self._h), "crt_retune")

@@ -38,6 +38,7 @@ struct BuildState {
     DeviceBuffer dp_cost, dp_choice, dp_parent, dp_depth, dp_list, dp_hist;      // collapse table (bvh_wide.hip)
     DeviceBuffer refit_list[2], refit_count[2];      // parked climbers between the stages of the LBVH refit
     uint32_t n_wide = 0, wide_levels = 0;
+    uint32_t wide_levels_hint = 0;                   // depth of the previous collapse (build_wide plans its launches with it)
     uint32_t pair_depth = 0;                         // levels of the SAH-refined pair tree (0: not measured, LBVH <= 95)
     bool pairs_valid = false;                        // false after a CRT_BVH_WIDE_DIRECT build: no pair tree, only the 8-wide one
     bool fuse_dp = false;                            // build_sah should make the wide collapse's table while it builds (set by build_bvh: CRT_BVH_SAH_REFINE | CRT_BVH_WIDE)
@@ -53,6 +54,7 @@ struct BuildState {
     uint32_t *host_lc = nullptr;                     // pinned copy of the device's level table (+ overflow word)
     hipEvent_t ev_counts = nullptr;
     bool counts_pending = false;
+    const uint32_t *sort_error_dev = nullptr;        // static builds through bvh_sort.hip: the sort's error word, looked at by crt_bvh_build after its wait
     bool records_fresh = false;                      // tri_shade / plo centroids / scene_bounds describe the triangles as they are now (animate_tris wrote them)
 };
 
@@ -85,6 +87,8 @@ bool refit_wide(hipStream_t stream, const BuildInput &in, BuildState &st, float 
 // bvh_sort.hip: LSD radix sort of 64-bit keys over bits [bit_lo, bit_hi), keys only; enqueue-only.  *sorted = the buffer that
 // holds the result; *error_word = a device word that is non-zero afterwards if a look-back wait gave up (never seen).
 size_t radix_sort_scratch_bytes(uint32_t n);
+bool radix_sort_u64(hipStream_t stream, uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n, uint32_t bit_lo, uint32_t bit_hi,
+                    void *scratch, const uint64_t **sorted, const uint32_t **sorted_vals, const uint32_t **error_word, std::string &err);
 bool radix_sort_keys_u64(hipStream_t stream, uint64_t *keys_a, uint64_t *keys_b, uint32_t n, uint32_t bit_lo, uint32_t bit_hi, void *scratch,
                          const uint64_t **sorted, const uint32_t **error_word, std::string &err);
 bool animate_tris(hipStream_t stream, uint32_t n, const crt_tri *rest, crt_tri *out, float frame, float amplitude, BuildState *st, std::string &err);

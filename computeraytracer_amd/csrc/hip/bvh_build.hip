@@ -575,6 +575,7 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     const uint32_t n = in.n_spheres + in.n_quads + in.n_tris;
     st.n_prims = n;
     st.n_pairs = n == 0 ? 0 : (n == 1 ? 1 : n - 1);
+    if (st.wide_levels) st.wide_levels_hint = st.wide_levels;
     st.n_wide = 0; st.wide_levels = 0; st.levels_measured = false; st.pair_depth = 0; st.dp_fused = false;
     const bool wide = (flags & CRT_BVH_WIDE) != 0;
     // CRT_BVH_WIDE_DIRECT (bvh_direct.hip): the 8-wide tree straight from the sorted keys; no pair tree and none of its scratch
@@ -643,8 +644,13 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     // fills, i.e. 2.64 instead of 2.49 ms per config-5 frame: rocPRIM stays the default ("if it cannot
     // beat rocPRIM, keep rocPRIM and write the measured reason").  The sort is correct (tests/test_gpu_sort.py) and stays
     // in the tree as the starting point: its ranking step serialises sixteen LDS round trips per wave and tile.
-    static const bool env_own_sort = [] { const char *e = getenv("CRT_BVH_SORT"); return e && std::string(e) == "onesweep"; }();
-    const bool own_sort = idx_bits != 0 && n > (1u << 20) && env_own_sort;
+    static const std::string env_sort = [] { const char *e = getenv("CRT_BVH_SORT"); return std::string(e ? e : ""); }();
+    // The (code, primitive) PAIR sorts of static builds of up to a million primitives (where rocPRIM falls back to a merge
+    // sort: 17 launches, 137 us for 225 k pairs) can go through it too, with 1024-key tiles: 143 us (eight digit passes of
+    // 14.4 us, whose look-back chains and ranking steps are latency, plus 19 us for a histogram whose top digits all hit the
+    // same LDS words), so there too the library stays the default.
+    const bool own_sort = env_sort == "onesweep" && ((idx_bits != 0 && n > (1u << 20)) || (idx_bits == 0 && !direct && n <= (1u << 20) && n >= 2));
+    st.sort_error_dev = nullptr;
     if (!ensure(st.temp, std::max(std::max(sort_bytes, scan_bytes), own_sort ? radix_sort_scratch_bytes(n) : (size_t)0), err)) return false;
 
     // the animation pass already left records, centroids and centroid bounds of exactly these triangles (animate_tris)
@@ -673,14 +679,17 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     HIP_TRY(hipGetLastError());
     size_t tb = st.temp.bytes;
     const uint64_t *keys = nullptr; const uint32_t *sort_error = nullptr;
+    const uint32_t *own_vals = nullptr;
     if (own_sort) {
-        if (!radix_sort_keys_u64(stream, (uint64_t *)st.keys.ptr, (uint64_t *)st.keys_alt.ptr, n, idx_bits, idx_bits + key_bits, st.temp.ptr, &keys, &sort_error, err)) return false;
+        if (!radix_sort_u64(stream, (uint64_t *)st.keys.ptr, (uint64_t *)st.keys_alt.ptr, idx_bits ? nullptr : (uint32_t *)st.vals.ptr, idx_bits ? nullptr : (uint32_t *)st.vals_alt.ptr,
+                            n, idx_bits, idx_bits + key_bits, st.temp.ptr, &keys, &own_vals, &sort_error, err)) return false;
+        if (!direct) st.sort_error_dev = sort_error;
     } else {
         if (idx_bits) HIP_TRY(rocprim::radix_sort_keys(st.temp.ptr, tb, dkeys, n, idx_bits, idx_bits + key_bits, stream));
         else HIP_TRY(rocprim::radix_sort_pairs(st.temp.ptr, tb, dkeys, dvals, n, 0, key_bits, stream));
         keys = dkeys.current();
     }
-    const uint32_t *vals = dvals.current();
+    const uint32_t *vals = (own_sort && !idx_bits) ? own_vals : dvals.current();
 
     if (direct) {
         const uint32_t idx_mask = (uint32_t)((1ull << idx_bits) - 1ull);

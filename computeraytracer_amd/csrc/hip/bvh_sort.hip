@@ -24,8 +24,9 @@
 
 namespace crt {
 
-constexpr uint32_t kRsItems = 16;                     // keys per thread
-constexpr uint32_t kRsTile = 256 * kRsItems;          // keys per tile
+constexpr uint32_t kRsItemsLarge = 16, kRsItemsSmall = 4;      // keys per thread: 4096-key tiles, 1024-key tiles up to a million keys (a
+                                                                // 225 k-key sort is 55 tiles of 4096: a fifth of the chip, each ranking 16 steps in a row)
+constexpr uint32_t kRsSmallMax = 1u << 20;
 constexpr uint32_t kRsBins = 256;
 constexpr uint32_t kRsMaxPasses = 8;
 constexpr uint32_t kFlagAgg = 1u << 30, kFlagPrefix = 2u << 30, kValueMask = (1u << 30) - 1u;
@@ -63,9 +64,13 @@ __global__ __launch_bounds__(256) void k_rs_scan(uint32_t *hist) {
     h[threadIdx.x] = s[threadIdx.x] - v;
 }
 
-__global__ __launch_bounds__(256) void k_rs_pass(const uint64_t *in, uint64_t *out, uint32_t n, uint32_t shift, uint32_t digit_mask, const uint32_t *gbase,
-                                                 uint32_t *status, uint32_t *ticket, uint32_t *error_flag) {
-    __shared__ uint64_t s_keys[kRsTile];              // 32 KiB: the tile in sorted order
+// PAIRS: a 32-bit value travels with every key (vin -> vout).
+template <uint32_t kRsItems, bool PAIRS>
+__global__ __launch_bounds__(256) void k_rs_pass(const uint64_t *in, uint64_t *out, const uint32_t *vin, uint32_t *vout, uint32_t n, uint32_t shift, uint32_t digit_mask,
+                                                 const uint32_t *gbase, uint32_t *status, uint32_t *ticket, uint32_t *error_flag) {
+    constexpr uint32_t kRsTile = 256 * kRsItems;
+    __shared__ uint64_t s_keys[kRsTile];              // the tile in sorted order (32 KiB at 16 keys per thread)
+    __shared__ uint32_t s_vals[PAIRS ? kRsTile : 1];
     __shared__ uint32_t s_wave[4][kRsBins];           // per-wave digit counters, then per-wave exclusive offsets
     __shared__ uint32_t s_start[kRsBins];             // end (exclusive) of a digit's run inside the sorted tile
     __shared__ uint32_t s_scan[kRsBins];
@@ -81,6 +86,7 @@ __global__ __launch_bounds__(256) void k_rs_pass(const uint64_t *in, uint64_t *o
     const uint32_t cnt = min(kRsTile, n - base);
     // ---- load + rank: wave w owns keys [w * 1024, w * 1024 + 1024) of the tile, step i covers 64 consecutive keys
     uint64_t key[kRsItems];
+    uint32_t val[kRsItems];
     uint32_t rank[kRsItems];
     const uint32_t wbase = wave * 64u * kRsItems;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -88,6 +94,7 @@ __global__ __launch_bounds__(256) void k_rs_pass(const uint64_t *in, uint64_t *o
     for (uint32_t i = 0; i < kRsItems; i++) {
         const uint32_t idx = wbase + i * 64u + lane;
         key[i] = idx < cnt ? in[base + idx] : ~0ull;
+        val[i] = (PAIRS && idx < cnt) ? vin[base + idx] : 0u;
     }
 #pragma unroll
     for (uint32_t i = 0; i < kRsItems; i++) {
@@ -154,7 +161,9 @@ __global__ __launch_bounds__(256) void k_rs_pass(const uint64_t *in, uint64_t *o
         if (idx < cnt) {
             const uint32_t d = (uint32_t)(key[i] >> shift) & digit_mask;
             const uint32_t run_start = d ? s_start[d - 1] : 0u;
-            s_keys[run_start + s_wave[wave][d] + rank[i]] = key[i];
+            const uint32_t pos = run_start + s_wave[wave][d] + rank[i];
+            s_keys[pos] = key[i];
+            if (PAIRS) s_vals[pos] = val[i];
         }
     }
     __syncthreads();
@@ -167,50 +176,73 @@ __global__ __launch_bounds__(256) void k_rs_pass(const uint64_t *in, uint64_t *o
             const uint32_t d = (uint32_t)(k >> shift) & digit_mask;
             const uint32_t run_start = d ? s_start[d - 1] : 0u;
             out[s_gpos[d] + (p - run_start)] = k;
+            if (PAIRS) vout[s_gpos[d] + (p - run_start)] = s_vals[p];
         }
     }
 }
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return false; } } while (0)
 
+static uint32_t rs_tile(uint32_t n) { return 256u * (n <= kRsSmallMax ? kRsItemsSmall : kRsItemsLarge); }
+
 size_t radix_sort_scratch_bytes(uint32_t n) {
-    const size_t tiles = ((size_t)n + kRsTile - 1) / kRsTile;
+    const size_t tiles = ((size_t)n + rs_tile(n) - 1) / rs_tile(n);
     // per pass: status words of every tile; then the histograms, the tickets and the error word
     return kRsMaxPasses * tiles * kRsBins * 4 + kRsMaxPasses * kRsBins * 4 + 256;
 }
 
-// Sorts n keys over bits [bit_lo, bit_hi); keys_a holds the input, the result is in *sorted (keys_a or keys_b).
+// Sorts n keys over bits [bit_lo, bit_hi); keys_a (and vals_a, if values travel along: vals_a / vals_b both non-null) hold
+// the input, the result is in *sorted (keys_a or keys_b) and *sorted_vals (vals_a or vals_b).
 // scratch: radix_sort_scratch_bytes(n) bytes.  Enqueue-only.  error_flag (inside scratch, last word) is set if a look-back
 // spin gave up; the caller may read it at its next synchronisation point.
-bool radix_sort_keys_u64(hipStream_t stream, uint64_t *keys_a, uint64_t *keys_b, uint32_t n, uint32_t bit_lo, uint32_t bit_hi, void *scratch,
-                         const uint64_t **sorted, const uint32_t **error_word, std::string &err) {
+bool radix_sort_u64(hipStream_t stream, uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n, uint32_t bit_lo, uint32_t bit_hi,
+                    void *scratch, const uint64_t **sorted, const uint32_t **sorted_vals, const uint32_t **error_word, std::string &err) {
     *sorted = keys_a;
+    if (sorted_vals) *sorted_vals = vals_a;
     *error_word = nullptr;
     if (n < 2 || bit_hi <= bit_lo) return true;
+    const bool pairs = vals_a != nullptr && vals_b != nullptr;
     const uint32_t bits = bit_hi - bit_lo;
     const uint32_t n_pass = (bits + 7u) / 8u;
     if (n_pass > kRsMaxPasses) { err = "radix sort: more than 64 key bits"; return false; }
     if (n >= (1u << 30)) { err = "radix sort: fewer than 2^30 keys"; return false; }
     const uint32_t last_bits = bits - 8u * (n_pass - 1u);
-    const uint32_t tiles = (n + kRsTile - 1u) / kRsTile;
+    const uint32_t tile = rs_tile(n), tiles = (n + tile - 1u) / tile;
     uint32_t *status = (uint32_t *)scratch;
     uint32_t *hist = status + (size_t)kRsMaxPasses * tiles * kRsBins;
     uint32_t *ticket = hist + kRsMaxPasses * kRsBins;      // [0..7] tickets, [8] error flag
-    HIP_TRY(hipMemsetAsync(scratch, 0, (size_t)n_pass * tiles * kRsBins * 4, stream));
-    HIP_TRY(hipMemsetAsync(hist, 0, kRsMaxPasses * kRsBins * 4 + 256, stream));
+    // status words of the passes that run, the histograms, the tickets and the error word: one fill when they are adjacent
+    if (n_pass == kRsMaxPasses) HIP_TRY(hipMemsetAsync(scratch, 0, radix_sort_scratch_bytes(n), stream));
+    else {
+        HIP_TRY(hipMemsetAsync(scratch, 0, (size_t)n_pass * tiles * kRsBins * 4, stream));
+        HIP_TRY(hipMemsetAsync(hist, 0, kRsMaxPasses * kRsBins * 4 + 256, stream));
+    }
     hipLaunchKernelGGL(k_rs_histogram, dim3(std::min<uint32_t>((n + 255u) / 256u, 2048u)), dim3(256), 0, stream, (const uint64_t *)keys_a, n, bit_lo, n_pass, last_bits, hist);
     hipLaunchKernelGGL(k_rs_scan, dim3(n_pass), dim3(256), 0, stream, hist);
     uint64_t *src = keys_a, *dst = keys_b;
+    uint32_t *vsrc = vals_a, *vdst = vals_b;
     for (uint32_t p = 0; p < n_pass; p++) {
         const uint32_t mask = p + 1 == n_pass ? (1u << last_bits) - 1u : 255u;
-        hipLaunchKernelGGL(k_rs_pass, dim3(tiles), dim3(256), 0, stream, (const uint64_t *)src, dst, n, bit_lo + 8u * p, mask, (const uint32_t *)(hist + p * kRsBins),
-                           status + (size_t)p * tiles * kRsBins, ticket + p, ticket + 8);
-        std::swap(src, dst);
+        const uint32_t shift = bit_lo + 8u * p;
+        const uint32_t *gb = hist + p * kRsBins;
+        uint32_t *stt = status + (size_t)p * tiles * kRsBins;
+#define CRT_RS_LAUNCH(ITEMS, PAIRS) hipLaunchKernelGGL((k_rs_pass<ITEMS, PAIRS>), dim3(tiles), dim3(256), 0, stream, (const uint64_t *)src, dst, (const uint32_t *)vsrc, vdst, n, \
+                                                       shift, mask, gb, stt, ticket + p, ticket + 8)
+        if (tile == 256u * kRsItemsSmall) { if (pairs) CRT_RS_LAUNCH(kRsItemsSmall, true); else CRT_RS_LAUNCH(kRsItemsSmall, false); }
+        else { if (pairs) CRT_RS_LAUNCH(kRsItemsLarge, true); else CRT_RS_LAUNCH(kRsItemsLarge, false); }
+#undef CRT_RS_LAUNCH
+        std::swap(src, dst); std::swap(vsrc, vdst);
     }
     HIP_TRY(hipGetLastError());
     *sorted = src;
+    if (sorted_vals) *sorted_vals = vsrc;
     *error_word = ticket + 8;
     return true;
+}
+
+bool radix_sort_keys_u64(hipStream_t stream, uint64_t *keys_a, uint64_t *keys_b, uint32_t n, uint32_t bit_lo, uint32_t bit_hi, void *scratch,
+                         const uint64_t **sorted, const uint32_t **error_word, std::string &err) {
+    return radix_sort_u64(stream, keys_a, keys_b, nullptr, nullptr, n, bit_lo, bit_hi, scratch, sorted, nullptr, error_word, err);
 }
 
 }  // namespace crt

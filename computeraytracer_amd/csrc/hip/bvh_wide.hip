@@ -49,6 +49,7 @@
 #include "build_internal.h"
 #include "bvh_common.h"
 #include "bvh_dp.h"
+#include "bvh_wide_node.h"
 
 namespace crt {
 
@@ -111,246 +112,213 @@ __global__ void k_dp_level(const float4 *pairs, const uint32_t *list, uint32_t f
     choice[n] = w;
 }
 
-// The eight children of a node under construction live in registers: every index into c[] below comes from a fully
-// unrolled loop (a dynamically indexed array would be placed in scratch memory, which made the first version of this
-// kernel several times slower), and "element k" for a run-time k is a chain of selects.
-__device__ __forceinline__ void take_if(WideChild &dst, const WideChild &v, bool p) {      // field-wise selects, never a conditional store
+// ---- one wide node, eight lanes ---------------------------------------------------------------------------------------
+// A node is made by a group of EIGHT lanes, one per child.  (The first version gave a node to one thread, with its eight
+// children in registers behind select chains: ~5000 dependent instructions and up to seven dependent loads per node, and
+// since a level of the tree cannot start before the level above it has finished, every one of the ~12 levels cost that
+// chain: 0.21 of the 0.83 ms of a 225 k-triangle build.)  Now every child that the table dissolves loads its two halves in
+// the same round (lane l keeps the left one, a free lane takes the right one: at most three rounds where the old loop made
+// six trips), the greedy slot assignment is eight rounds of eight evaluations per lane plus a three-step reduction, and
+// the quantisation is bvh_wide_node.h's (one slot per lane).
+__device__ __forceinline__ uint32_t group_mask8(bool p) { return (uint32_t)((__ballot(p) >> (threadIdx.x & 56u)) & 0xFFull); }
+__device__ __forceinline__ uint32_t nth_bit8(uint32_t mask, uint32_t n) {      // position of the n-th set bit (8: there is none)
+    uint32_t r = 8u;
 #pragma unroll
-    for (int a = 0; a < 3; a++) { dst.lo[a] = p ? v.lo[a] : dst.lo[a]; dst.hi[a] = p ? v.hi[a] : dst.hi[a]; }
-    dst.link = p ? v.link : dst.link; dst.count = p ? v.count : dst.count; dst.budget = p ? v.budget : dst.budget; dst.eff = p ? v.eff : dst.eff;
+    for (int i = 7; i >= 0; i--) { const uint32_t below = (uint32_t)__builtin_popcount(mask & ((1u << i) - 1u)); r = (((mask >> i) & 1u) && below == n) ? (uint32_t)i : r; }
+    return r;
 }
-struct WideSet {
-    WideChild c[8];
-    __device__ __forceinline__ WideChild get(int k) const {
-        WideChild r = c[0];
+struct Child8 { float lo[3], hi[3]; uint32_t link, count, budget, eff; bool valid; };
+__device__ __forceinline__ void pull8(Child8 &c, uint32_t from, bool take) {      // every lane of the group calls this
+    Child8 r;
 #pragma unroll
-        for (int i = 1; i < 8; i++) take_if(r, c[i], i == k);
-        return r;
-    }
-    __device__ __forceinline__ void set(int k, const WideChild &v) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) take_if(c[i], v, i == k);
-    }
-};
+    for (int a = 0; a < 3; a++) { r.lo[a] = __shfl(c.lo[a], (int)from, 8); r.hi[a] = __shfl(c.hi[a], (int)from, 8); }
+    r.link = (uint32_t)__shfl((int)c.link, (int)from, 8); r.count = (uint32_t)__shfl((int)c.count, (int)from, 8);
+    r.budget = (uint32_t)__shfl((int)c.budget, (int)from, 8); r.eff = (uint32_t)__shfl((int)c.eff, (int)from, 8);
+    r.valid = __shfl((int)c.valid, (int)from, 8) != 0;
+    if (take) c = r;
+}
+// valid children to lanes 0 .. n - 1 of the group, in order
+__device__ __forceinline__ void compact8(Child8 &c, uint32_t sl) {
+    const uint32_t mask = group_mask8(c.valid);
+    const uint32_t from = nth_bit8(mask, sl);
+    pull8(c, from & 7u, true);
+    c.valid = from < 8u;
+}
 
-// One wide node: collapses the subtree of pair `src` into node `dst` of level `level`; its inner children are appended
-// to q_out (the queue of level + 1) and numbered next_base + position (next_base = nodes of levels 0 .. level).
-__device__ __forceinline__ void wide_emit(const float4 *pairs, const unsigned long long *choice, uint32_t level, uint32_t *level_count,
-                                          uint32_t next_base, uint32_t src, uint32_t dst, uint2 *q_out, float4 *wide, uint4 *links) {
-    {
-        WideSet S;
+// Collapses the subtree of pair `src` into node `dst` of level `level`; its inner children are appended to q_out (the queue
+// of level + 1) and numbered next_base + position (next_base = nodes of levels 0 .. level).  Called by whole waves;
+// active, src and dst are uniform over a group of eight lanes, sl = lane & 7.
+__device__ __forceinline__ void wide_emit8(const float4 *pairs, const unsigned long long *choice, uint32_t level, uint32_t *level_count, uint32_t next_base,
+                                           bool active, uint32_t src, uint32_t dst, uint2 *q_out, float4 *wide, uint32_t *links) {
+    const uint32_t sl = threadIdx.x & 7u;
+    Child8 c;
 #pragma unroll
-        for (int k = 0; k < 8; k++) { for (int a = 0; a < 3; a++) { S.c[k].lo[a] = 0.0f; S.c[k].hi[a] = 0.0f; } S.c[k].link = 0u; S.c[k].count = 0u; S.c[k].budget = 1u; S.c[k].eff = 0u; }
-        int n = 0;
-        {
-            WideChild a, b;
-            read_half(pairs + 4 * (size_t)src, a);
-            read_half(pairs + 4 * (size_t)src + 2, b);
-            if (choice) {      // best split of 8 slots, and the children's own tables
-                const unsigned long long w = choice[src];
-                const uint32_t k8 = (uint32_t)(w >> 18) & 7u;
-                a.budget = k8; b.budget = 8u - k8; a.eff = (uint32_t)(w >> 21) & 0x1FFFFFu; b.eff = (uint32_t)(w >> 42) & 0x1FFFFFu;
-            }
-            if (!pad_leaf(a.count)) { S.set(n, a); n++; }
-            if (!pad_leaf(b.count)) { S.set(n, b); n++; }
+    for (int a = 0; a < 3; a++) { c.lo[a] = 0.0f; c.hi[a] = 0.0f; }
+    c.link = 0u; c.count = 0u; c.budget = 1u; c.eff = 0u; c.valid = false;
+    if (active && sl < 2u) {
+        WideChild h;
+        read_half(pairs + 4 * (size_t)src + 2 * sl, h);
+#pragma unroll
+        for (int a = 0; a < 3; a++) { c.lo[a] = h.lo[a]; c.hi[a] = h.hi[a]; }
+        c.link = h.link; c.count = h.count;
+        if (choice) {      // best split of 8 slots, and the children's own tables
+            const unsigned long long w = choice[src];
+            const uint32_t k8 = (uint32_t)(w >> 18) & 7u;
+            c.budget = sl == 0u ? k8 : 8u - k8;
+            c.eff = (uint32_t)(w >> (sl == 0u ? 21 : 42)) & kDpEffMask;
         }
-        while (n < 8) {
-            int best = -1; float best_area = -1.0f; uint32_t best_link = 0, best_budget = 1;
-            if (choice) {
-                // an inner child that the table dissolves when offered its budget (eff > 1); any order gives the same set
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    if (k >= n || S.c[k].count != 0u || S.c[k].budget < 2u || best >= 0) continue;
-                    const uint32_t bud = S.c[k].budget > 7u ? 7u : S.c[k].budget;
-                    const uint32_t eff = (S.c[k].eff >> (3 * (bud - 1u))) & 7u;
-                    if (eff > 1u) { best = k; best_link = S.c[k].link; best_budget = eff; }
-                    else S.c[k].budget = 1u;      // stays a wide node of its own: do not look at it again
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    if (k >= n || S.c[k].count != 0u) continue;
-                    const float a = half_area3(S.c[k].lo, S.c[k].hi);
-                    if (a > best_area) { best_area = a; best = k; best_link = S.c[k].link; }
-                }
-            }
-            if (best < 0) break;
-            WideChild a, b;
-            read_half(pairs + 4 * (size_t)best_link, a);
-            read_half(pairs + 4 * (size_t)best_link + 2, b);
-            if (choice) {      // loaded together with the pair: the split of the slots it was granted and its children's tables
-                const unsigned long long w = choice[best_link];
-                const uint32_t kk = (uint32_t)(w >> (3 * (best_budget - 2u))) & 7u;
-                a.budget = kk; b.budget = best_budget - kk; a.eff = (uint32_t)(w >> 21) & 0x1FFFFFu; b.eff = (uint32_t)(w >> 42) & 0x1FFFFFu;
-            }
-            const bool pa = pad_leaf(a.count), pb = pad_leaf(b.count);
-            if (pa && pb) { S.set(best, S.get(n - 1)); n--; continue; }
-            if (pa) { S.set(best, b); continue; }
-            S.set(best, a);
-            if (!pb) { S.set(n, b); n++; }
-        }
-        // node box, origin (rounded down to 15 mantissa bits) and per-axis grid step
-        // All in single precision (the double-precision version of this block and of the quantisation below ran at a half to
-        // a sixteenth of the FP32 rate and was most of this kernel's time); conservative by construction, see below.
-        float lo[3], hi[3], origin[3]; uint32_t ebits[3]; float inv_scale[3];
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            lo[a] = S.c[0].lo[a]; hi[a] = S.c[0].hi[a];
-#pragma unroll
-            for (int k = 1; k < 8; k++) if (k < n) { lo[a] = fminf(lo[a], S.c[k].lo[a]); hi[a] = fmaxf(hi[a], S.c[k].hi[a]); }
-            uint32_t b = __float_as_uint(lo[a]), t = b & 0xFFFFFE00u;
-            if ((b & 0x80000000u) && t != b) t += 0x200u;          // negative: truncation moved it up, step one unit down
-            origin[a] = __uint_as_float(t);
-            // grid step 2^e with 255 * 2^e >= hi - origin.  ext carries a relative error of at most 2^-24 (one rounded
-            // subtraction), the division another 2^-24, so a quotient within 2^-20 of the next power of two takes that one.
-            const float ext = hi[a] - origin[a];
-            int e = -100;
-            if (ext > 0.0f) {
-                int x; const float m = frexpf(ext / 255.0f, &x);      // ext / 255 = m * 2^x, 0.5 <= m < 1
-                e = m > 0.999999f ? x + 1 : x;
-            }
-            if (!(ext <= 3.402823466e38f)) e = 122;                   // the subtraction overflowed (or a NaN box): 255 * 2^122 covers any finite extent
-            e = e < -100 ? -100 : e > 122 ? 122 : e;
-            ebits[a] = (uint32_t)(e + 127);
-            inv_scale[a] = __uint_as_float((uint32_t)(127 - e) << 23);      // 2^-e, exact (e in [-100, 122])
-        }
-        // slot assignment: greedy maximum of sum_a (slot bit a ? +1 : -1) * (child centroid - node centre)_a.
-        // slot_of: four bits per child; used / done: one bit per slot / child.
-        float dv[8][3];
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-#pragma unroll
-            for (int a = 0; a < 3; a++) dv[k][a] = (0.5f * S.c[k].lo[a] + 0.5f * S.c[k].hi[a]) - (0.5f * lo[a] + 0.5f * hi[a]);
-        uint32_t slot_of = 0, slot_used = 0, child_done = 0;
-        if (!choice) {
-            // The per-frame LBVH rebuild (no table): children in order of decreasing |d|_1 (the score of a child's ideal slot, so the order in which the greedy rule
-            // below serves children whose ideal slot is still free); each takes its best free slot.  An eighth of the
-            // evaluations of the full greedy rule; on the headline scene it costs 0.14 % more node visits, so static (SAH +
-            // table) builds keep the full rule.
-            float l1[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) l1[k] = (fabsf(dv[k][0]) + fabsf(dv[k][1])) + fabsf(dv[k][2]);
-            for (int it = 0; it < n; it++) {
-                float top = -1.0f; int bk = -1;
-#pragma unroll
-                for (int k = 0; k < 8; k++) if (k < n && !((child_done >> k) & 1u) && l1[k] > top) { top = l1[k]; bk = k; }
-                if (bk < 0) bk = __builtin_ctz(~child_done & ((1u << n) - 1u));      // only NaNs left
-                float d0 = dv[0][0], d1 = dv[0][1], d2 = dv[0][2];
-#pragma unroll
-                for (int k = 1; k < 8; k++) { d0 = k == bk ? dv[k][0] : d0; d1 = k == bk ? dv[k][1] : d1; d2 = k == bk ? dv[k][2] : d2; }
-                float best = -3.402823466e38f; int bs = -1;
-#pragma unroll
-                for (int sl = 0; sl < 8; sl++) {
-                    const float v = ((sl & 1) ? d0 : -d0) + ((sl & 2) ? d1 : -d1) + ((sl & 4) ? d2 : -d2);
-                    if (!((slot_used >> sl) & 1u) && v > best) { best = v; bs = sl; }
-                }
-                if (bs < 0) bs = __builtin_ctz(~slot_used & 0xFFu);
-                slot_of |= (uint32_t)bs << (4 * bk); child_done |= 1u << bk; slot_used |= 1u << bs;
-            }
-        } else
-        for (int it = 0; it < n; it++) {
-            float best = -3.402823466e38f; int bk = -1, bs = -1;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (k >= n || ((child_done >> k) & 1u)) continue;
-#pragma unroll
-                for (int sl = 0; sl < 8; sl++) {
-                    if ((slot_used >> sl) & 1u) continue;
-                    const float v = ((sl & 1) ? dv[k][0] : -dv[k][0]) + ((sl & 2) ? dv[k][1] : -dv[k][1]) + ((sl & 4) ? dv[k][2] : -dv[k][2]);
-                    if (v > best) { best = v; bk = k; bs = sl; }
-                }
-            }
-            if (bk < 0) {            // only NaN costs left: first free pair
-                bk = __builtin_ctz(~child_done & ((1u << n) - 1u));
-                bs = __builtin_ctz(~slot_used & 0xFFu);
-            }
-            slot_of |= (uint32_t)bs << (4 * bk); child_done |= 1u << bk; slot_used |= 1u << bs;
-        }
-        uint32_t imask = 0, n_inner = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) if (k < n && S.c[k].count == 0u) { imask |= 1u << ((slot_of >> (4 * k)) & 7u); n_inner++; }
-        uint32_t qpos = 0;
-        if (n_inner) qpos = atomicAdd(&level_count[level + 1], n_inner);
-        const uint32_t child_base = next_base + qpos;
-        // quantise: empty slots keep qlo = 255, qhi = 0
-        uint32_t q[6][2];     // qlo x,y,z, qhi x,y,z; two dwords of four slots
-        uint32_t link[8];
-#pragma unroll
-        for (int a = 0; a < 3; a++) { q[a][0] = q[a][1] = 0xFFFFFFFFu; q[3 + a][0] = q[3 + a][1] = 0u; }
-#pragma unroll
-        for (int sl = 0; sl < 8; sl++) link[sl] = kWideEmptyLink;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (k >= n) continue;
-            const uint32_t sl = (slot_of >> (4 * k)) & 7u, sh = 8u * (sl & 3u);
-            const bool upper = sl >= 4u;
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                // x = (plane - origin) / 2^e in [0, 255]: the subtraction rounds once (relative 2^-24, i.e. at most 2^-16 in x),
-                // the scaling is exact; 2^-10 of slack towards the outside makes floor / ceil safe against that error, and
-                // costs a grid step only for planes within 2^-10 of a grid line.
-                const float xl = (S.c[k].lo[a] - origin[a]) * inv_scale[a], xh = (S.c[k].hi[a] - origin[a]) * inv_scale[a];
-                float fl = floorf(xl - 0.0009765625f), fh = ceilf(xh + 0.0009765625f);
-                fl = (fl >= 0.0f && fl <= 255.0f) ? fl : 0.0f;             // below the grid, or NaN / inf from an overflowed difference: the whole range
-                fh = (fh >= 0.0f && fh <= 255.0f) ? fh : 255.0f;
-                const uint32_t clr = ~(255u << sh), vl = (uint32_t)fl << sh, vh = (uint32_t)fh << sh;
-                if (upper) { q[a][1] = (q[a][1] & clr) | vl; q[3 + a][1] |= vh; }
-                else { q[a][0] = (q[a][0] & clr) | vl; q[3 + a][0] |= vh; }
-            }
-            uint32_t lk;
-            if (S.c[k].count == 0u) {
-                const uint32_t r = (uint32_t)__builtin_popcount(imask & ((1u << sl) - 1u));     // inner children are numbered in slot order
-                lk = child_base + r;
-                q_out[qpos + r] = make_uint2(S.c[k].link, lk);
-            } else {
-                const uint32_t kind = S.c[k].count >> 28, cnt = S.c[k].count & 0x0FFFFFFFu;
-                lk = kWideLeafTag | (kind << 29) | ((cnt - 1u) << 26) | S.c[k].link;
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 8; s2++) link[s2] = (uint32_t)s2 == sl ? lk : link[s2];
-        }
-        float4 *o = wide + (size_t)kWideStrideF4 * dst;
-        o[0] = make_float4(__uint_as_float(__float_as_uint(origin[0]) | ebits[0]), __uint_as_float(__float_as_uint(origin[1]) | ebits[1]),
-                           __uint_as_float(__float_as_uint(origin[2]) | ebits[2]), __uint_as_float((child_base << 8) | imask));
-        o[1] = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
-        o[2] = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
-        o[3] = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
-        links[2 * (size_t)dst] = make_uint4(link[0], link[1], link[2], link[3]);
-        links[2 * (size_t)dst + 1] = make_uint4(link[4], link[5], link[6], link[7]);
+        c.valid = !pad_leaf(h.count);
     }
+    if (__ballot(active && sl < 2u && !c.valid) != 0ull) compact8(c, sl);
+    // ---- dissolve: with the table, every inner child that the table dissolves when offered its budget (eff > 1), all of
+    // them in the same round; without it (the per-frame LBVH rebuild), the inner child of largest area, one per round,
+    // until there are eight
+    for (;;) {
+        const uint32_t n = (uint32_t)__builtin_popcount(group_mask8(c.valid));
+        bool dis = false; uint32_t grant = 0u;
+        if (choice) {
+            if (c.valid && c.count == 0u && c.budget >= 2u) {
+                const uint32_t bud = c.budget > 7u ? 7u : c.budget;
+                const uint32_t eff = (c.eff >> (3u * (bud - 1u))) & 7u;
+                if (eff > 1u) { dis = true; grant = eff; } else c.budget = 1u;      // stays a wide node of its own
+            }
+        } else {
+            const float area = (c.valid && c.count == 0u) ? half_area3(c.lo, c.hi) : -1.0f;
+            float best = area > -1.0f ? area : -1.0f; uint32_t who = area > -1.0f ? sl : 8u;      // (a NaN area is never chosen)
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) {
+                const float ob = __shfl_xor(best, off, 8); const uint32_t ow = (uint32_t)__shfl_xor((int)who, off, 8);
+                const bool take = ob > best || (ob == best && ow < who);
+                best = take ? ob : best; who = take ? ow : who;
+            }
+            dis = n < 8u && who == sl;
+        }
+        if (__ballot(dis) == 0ull) break;
+        const uint32_t dmask = group_mask8(dis), nd = (uint32_t)__builtin_popcount(dmask);
+        // lane l (dissolving) takes the left half of its pair; lane n + r takes the right half of the r-th dissolving lane's
+        const uint32_t donor = nth_bit8(dmask, sl - n) & 7u;
+        const uint32_t link_d = (uint32_t)__shfl((int)c.link, (int)donor, 8), grant_d = (uint32_t)__shfl((int)grant, (int)donor, 8);
+        const bool taker = active && sl >= n && sl < n + nd;
+        if (dis || taker) {
+            const uint32_t lk = dis ? c.link : link_d, gr = dis ? grant : grant_d, side = dis ? 0u : 1u;
+            WideChild h;
+            read_half(pairs + 4 * (size_t)lk + 2 * side, h);
+#pragma unroll
+            for (int a = 0; a < 3; a++) { c.lo[a] = h.lo[a]; c.hi[a] = h.hi[a]; }
+            c.link = h.link; c.count = h.count; c.budget = 1u; c.eff = 0u;
+            if (choice) {      // loaded together with the pair: the split of the slots it was granted and its children's tables
+                const unsigned long long w = choice[lk];
+                const uint32_t kk = (uint32_t)(w >> (3u * (gr - 2u))) & 7u;
+                c.budget = side ? gr - kk : kk;
+                c.eff = (uint32_t)(w >> (side ? 42 : 21)) & kDpEffMask;
+            }
+            c.valid = !pad_leaf(h.count);
+        }
+        if (__ballot((dis || taker) && !c.valid) != 0ull) compact8(c, sl);
+    }
+    // ---- node box and the children's offsets from its centre
+    float lo[3], hi[3], dv[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float l = c.valid ? c.lo[a] : 3.402823466e38f, h = c.valid ? c.hi[a] : -3.402823466e38f;
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) { l = fminf(l, __shfl_xor(l, off, 8)); h = fmaxf(h, __shfl_xor(h, off, 8)); }
+        lo[a] = l; hi[a] = h;
+        dv[a] = (0.5f * c.lo[a] + 0.5f * c.hi[a]) - (0.5f * l + 0.5f * h);
+    }
+    // ---- slot assignment: greedy maximum of sum_a (slot bit a ? +1 : -1) * (child centroid - node centre)_a over all
+    // (child, free slot) pairs; the per-frame LBVH rebuild (no table) serves the children in order of decreasing |d|_1
+    // instead, each taking its best free slot (0.14 % more node visits on the headline scene, an eighth of the work when
+    // this was one thread's loop; kept so that those trees stay what they were).  Ties: lowest lane, lowest slot.
+    const float l1 = (fabsf(dv[0]) + fabsf(dv[1])) + fabsf(dv[2]);
+    uint32_t used = 0u, my_slot = 8u;
+    for (int it = 0; it < 8; it++) {
+        const bool cand = c.valid && my_slot == 8u;
+        float bv = -3.402823466e38f; uint32_t bs = (uint32_t)__builtin_ctz((~used & 0xFFu) | 0x100u);      // only NaN scores: the first free slot
+#pragma unroll
+        for (int s2 = 0; s2 < 8; s2++) {
+            const float v = ((s2 & 1) ? dv[0] : -dv[0]) + ((s2 & 2) ? dv[1] : -dv[1]) + ((s2 & 4) ? dv[2] : -dv[2]);
+            if (!((used >> s2) & 1u) && v > bv) { bv = v; bs = (uint32_t)s2; }
+        }
+        float key = choice ? bv : l1;
+        key = (cand && key == key) ? key : -3.402823466e38f;
+        float bk = key; uint32_t who = cand ? sl : 8u;
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            const float ob = __shfl_xor(bk, off, 8); const uint32_t ow = (uint32_t)__shfl_xor((int)who, off, 8);
+            const bool take = ow < 8u && (who == 8u || ob > bk || (ob == bk && ow < who));
+            bk = take ? ob : bk; who = take ? ow : who;
+        }
+        if (__ballot(who < 8u) == 0ull) break;
+        const uint32_t ws = (uint32_t)__shfl((int)bs, (int)(who & 7u), 8);
+        if (who < 8u) { used |= 1u << ws; if (who == sl) my_slot = ws; }
+    }
+    // ---- to slot order: lane s takes the child that got slot s
+    uint32_t from = 8u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const uint32_t sj = (uint32_t)__shfl((int)my_slot, j, 8); from = sj == sl ? (uint32_t)j : from; }
+    pull8(c, from & 7u, true);
+    c.valid = c.valid && from < 8u;
+    const uint32_t imask = group_mask8(c.valid && c.count == 0u);
+    const uint32_t n_inner = (uint32_t)__builtin_popcount(imask);
+    uint32_t qpos = 0u;
+    if (active && sl == 0u && n_inner) qpos = atomicAdd(&level_count[level + 1], n_inner);
+    qpos = (uint32_t)__shfl((int)qpos, 0, 8);
+    const uint32_t child_base = next_base + qpos;
+    uint32_t lk = kWideEmptyLink;
+    if (c.valid) {
+        if (c.count == 0u) {      // inner children are numbered in slot order
+            const uint32_t r = (uint32_t)__builtin_popcount(imask & ((1u << sl) - 1u));
+            lk = child_base + r;
+            if (active) q_out[qpos + r] = make_uint2(c.link, lk);
+        } else {
+            const uint32_t kind = c.count >> 28, cnt = c.count & 0x0FFFFFFFu;
+            lk = kWideLeafTag | (kind << 29) | ((cnt - 1u) << 26) | c.link;
+        }
+    }
+    if (active) links[8 * (size_t)dst + sl] = lk;
+    wide_node_finish(active, sl, dst, (child_base << 8) | imask, c.lo, c.hi, c.valid, wide, nullptr, nullptr);
 }
 
 // level_count[l] = wide nodes of level l (queue length); level l reads queue l & 1 and appends to the other one.
-// Levels below *first_level were already emitted by k_wide_top.
-__global__ __launch_bounds__(128) void k_wide_level(const float4 *pairs, const unsigned long long *choice, uint32_t level, uint32_t *level_count,
-                                                    const uint32_t *first_level, const uint2 *q_in, uint2 *q_out, float4 *wide, uint4 *links) {
+// Levels below *first_level were already emitted by k_wide_top.  Eight lanes per node.
+constexpr uint32_t kWideLevelThreads = 256;
+__global__ __launch_bounds__(kWideLevelThreads) void k_wide_level(const float4 *pairs, const unsigned long long *choice, uint32_t level, uint32_t *level_count,
+                                                                  const uint32_t *first_level, const uint2 *q_in, uint2 *q_out, float4 *wide, uint32_t *links) {
     if (level < *first_level) return;
     const uint32_t n_in = level_count[level];
     uint32_t next_base = 0;                         // nodes of levels 0..level = index of the first node of level + 1
     for (uint32_t l = 0; l <= level; l++) next_base += level_count[l];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
-        const uint2 w = q_in[i];
-        wide_emit(pairs, choice, level, level_count, next_base, w.x, w.y, q_out, wide, links);
+    const uint32_t stride = (gridDim.x * blockDim.x) >> 3;
+    for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;; i += stride) {
+        const bool active = i < n_in;
+        if (__ballot(active) == 0ull) break;
+        const uint2 w = active ? q_in[i] : make_uint2(0u, 0u);
+        wide_emit8(pairs, choice, level, level_count, next_base, active, w.x, w.y, q_out, wide, links);
     }
 }
 
-// The first levels hold 1, <= 8, <= 64, ... nodes; a launch per level costs ~25 us of dependent-load latency each however
-// few nodes it has.  One workgroup walks the levels that fit its threads, one node per thread, and leaves the first
+// The first levels hold 1, <= 8, <= 64 nodes; a launch per level costs a kernel's start-up and drain each however few
+// nodes it has.  One workgroup walks the levels that fit its threads, eight threads per node, and leaves the first
 // level it did not do in *first_level (k_wide_level skips the earlier ones).  Everything it hands from one level to the
 // next (queue entries, level counts) stays inside the workgroup: workgroup-scope release / acquire around the barrier.
-constexpr uint32_t kWideTopThreads = 512;
+constexpr uint32_t kWideTopThreads = 1024;
 __global__ __launch_bounds__(kWideTopThreads) void k_wide_top(const float4 *pairs, const unsigned long long *choice, uint32_t *level_count, uint32_t max_levels,
-                                                              uint32_t *first_level, uint2 *q0, uint2 *q1, float4 *wide, uint4 *links) {
+                                                              uint32_t *first_level, uint2 *q0, uint2 *q1, float4 *wide, uint32_t *links, const float *root_row) {
+    // (the pair tree's height, which the fused table left in word 7 of the root's row, rides to the host with the level table)
+    if (threadIdx.x == 0 && root_row) level_count[kWideMaxLevels + 3] = __float_as_uint(root_row[7]);
     uint32_t next_base = 0, level = 0;
     for (; level < max_levels; level++) {
         const uint32_t n_in = __hip_atomic_load(&level_count[level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (n_in == 0u || n_in > kWideTopThreads) break;
+        if (n_in == 0u || n_in > kWideTopThreads / 8u) break;
         next_base += n_in;
         const uint2 *q_in = (level & 1u) ? q1 : q0;
         uint2 *q_out = (level & 1u) ? q0 : q1;
-        if (threadIdx.x < n_in) {
-            const uint2 w = q_in[threadIdx.x];
-            wide_emit(pairs, choice, level, level_count, next_base, w.x, w.y, q_out, wide, links);
+        const uint32_t i = threadIdx.x >> 3;
+        const bool active = i < n_in;
+        if (__ballot(active) != 0ull) {
+            const uint2 w = active ? q_in[i] : make_uint2(0u, 0u);
+            wide_emit8(pairs, choice, level, level_count, next_base, active, w.x, w.y, q_out, wide, links);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
@@ -387,9 +355,9 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
     // every wide node consumes at least one pair, so n_pairs bounds the node count and every level's queue
     if (!ensure_w(st.wide, (size_t)st.n_pairs * (kWideStrideF4 * sizeof(float4) + 32), err)) return false;      // nodes, then 32 bytes of links per node
     st.wide_cap = st.n_pairs;
-    uint4 *links = (uint4 *)((float4 *)st.wide.ptr + (size_t)kWideStrideF4 * st.wide_cap);
+    uint32_t *links = (uint32_t *)((float4 *)st.wide.ptr + (size_t)kWideStrideF4 * st.wide_cap);
     if (!ensure_w(st.wide_queue[0], (size_t)st.n_pairs * 8, err) || !ensure_w(st.wide_queue[1], (size_t)st.n_pairs * 8, err)) return false;
-    if (!ensure_w(st.wide_levels_dev, (kWideMaxLevels + 3) * 4, err)) return false;
+    if (!ensure_w(st.wide_levels_dev, (kWideMaxLevels + 4) * 4, err)) return false;
     uint32_t *lc = (uint32_t *)st.wide_levels_dev.ptr;
     // ---- the table (only when the pairs' depths were measured, i.e. after the SAH refinement: the per-frame LBVH rebuild
     // keeps the cheaper greedy rule): buckets by depth -> one launch per depth, deepest first ------------------------------
@@ -412,24 +380,27 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
     hipLaunchKernelGGL(k_wide_init, dim3(1), dim3(128), 0, stream, lc, kWideMaxLevels + 1, (uint2 *)st.wide_queue[0].ptr);
     uint32_t *first_level = lc + kWideMaxLevels + 2;
     hipLaunchKernelGGL(k_wide_top, dim3(1), dim3(kWideTopThreads), 0, stream, (const float4 *)st.pairs.ptr, choice, lc, kWideMaxLevels, first_level,
-                       (uint2 *)st.wide_queue[0].ptr, (uint2 *)st.wide_queue[1].ptr, (float4 *)st.wide.ptr, links);
-    const uint32_t grid = std::min<uint32_t>(2048u, (st.n_pairs + 127u) / 128u);
-    uint32_t host_lc[kWideMaxLevels + 3];
-    uint32_t root_word = 0; bool height_read = false;
-    uint32_t level = 1;      // k_wide_top always does level 0 (one node)
-    for (;;) {
-        const uint32_t chunk_end = std::min<uint32_t>(level + 8u, kWideMaxLevels);
+                       (uint2 *)st.wide_queue[0].ptr, (uint2 *)st.wide_queue[1].ptr, (float4 *)st.wide.ptr, links,
+                       st.dp_fused ? (const float *)st.dp_cost.ptr : (const float *)nullptr);
+    const uint32_t grid = std::min<uint32_t>(2048u, (st.n_pairs * 8u + kWideLevelThreads - 1u) / kWideLevelThreads);
+    uint32_t host_lc[kWideMaxLevels + 4];
+    bool height_read = false;
+    uint32_t level = 3;      // k_wide_top always does levels 0, 1 and 2 (1, <= 8, <= 64 nodes; a launch that finds its level done still costs ~4.5 us)
+    // launches are planned blind, a chunk of levels at a time; the first chunk is as long as the previous build's tree was
+    // deep (a rebuild of the same scene then needs one chunk and no launch that finds nothing to do), else eight levels
+    uint32_t chunk = st.wide_levels_hint > level ? st.wide_levels_hint - level : 8u;
+    for (;; chunk = 4u) {
+        const uint32_t chunk_end = std::min<uint32_t>(level + chunk, kWideMaxLevels);
         for (; level < chunk_end; level++)
-            hipLaunchKernelGGL(k_wide_level, dim3(grid), dim3(128), 0, stream, (const float4 *)st.pairs.ptr, choice, level, lc, (const uint32_t *)first_level,
+            hipLaunchKernelGGL(k_wide_level, dim3(grid), dim3(kWideLevelThreads), 0, stream, (const float4 *)st.pairs.ptr, choice, level, lc, (const uint32_t *)first_level,
                                (const uint2 *)st.wide_queue[level & 1].ptr, (uint2 *)st.wide_queue[(level & 1) ^ 1].ptr,
                                (float4 *)st.wide.ptr, links);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(host_lc, lc, (kWideMaxLevels + 3) * 4, hipMemcpyDeviceToHost, stream));
-        if (st.dp_fused && !height_read) HIP_TRY(hipMemcpyAsync(&root_word, (const float *)st.dp_cost.ptr + 7, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(host_lc, lc, (kWideMaxLevels + 4) * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (st.dp_fused && !height_read) {      // the pair tree's height came with the table (bvh_sah.hip): the pair tracers' stacks bound it
             height_read = true;
-            st.pair_depth = root_word >> 21;
+            st.pair_depth = host_lc[kWideMaxLevels + 3] >> 21;
             if (st.pair_depth > pair_depth_limit()) {
                 err = "SAH-refined tree is " + std::to_string(st.pair_depth) + " levels deep; the pair traversal stacks hold " + std::to_string(pair_depth_limit());
                 return false;

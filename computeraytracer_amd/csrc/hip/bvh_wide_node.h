@@ -18,7 +18,8 @@ __device__ __forceinline__ uint32_t or_quad(uint32_t v) {      // OR over the fo
 }
 
 // Every lane of the wave calls this (shuffles inside); `active` is uniform over a group of eight lanes.  area (optional):
-// receives the node's surface area in every lane of the group (0 for an inactive group).
+// receives the node's surface area in every lane of the group (0 for an inactive group).  box (optional): the node's exact
+// box for its parent (bottom-up passes).
 __device__ __forceinline__ void wide_node_finish(bool active, uint32_t sl, uint32_t id, uint32_t hdr, const float clo[3], const float chi[3], bool valid,
                                                  float4 *wide, float4 *box, float *area) {
     // node box over the group (a NaN coordinate of a primitive stays in its own slot's box: fminf / fmaxf drop it here,
@@ -81,10 +82,10 @@ __device__ __forceinline__ void wide_node_finish(bool active, uint32_t sl, uint3
     if (sl == 0u) {
         o[0] = make_float4(__uint_as_float(__float_as_uint(origin[0]) | ebits[0]), __uint_as_float(__float_as_uint(origin[1]) | ebits[1]),
                            __uint_as_float(__float_as_uint(origin[2]) | ebits[2]), __uint_as_float(hdr));
-        box[2 * (size_t)id] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        if (box) box[2 * (size_t)id] = make_float4(lo[0], lo[1], lo[2], 0.0f);
     } else if (sl == 1u) {
         o[1] = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
-        box[2 * (size_t)id + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+        if (box) box[2 * (size_t)id + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
     } else if (sl == 2u) o[2] = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
     else if (sl == 3u) o[3] = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
 }

@@ -490,6 +490,12 @@ int crt_bvh_build(crt_context *ctx, uint32_t flags, float *build_ms) {
     ctx->last_build_ms = ms;
     ctx->build_time_pending = false;
     if (build_ms) *build_ms = ms;
+    if (ctx->build.sort_error_dev) {      // the hand-written key sort of a static build: did a look-back wait give up? (never seen)
+        uint32_t flag = 0;
+        CTX_HIP(hipMemcpy(&flag, ctx->build.sort_error_dev, 4, hipMemcpyDeviceToHost));
+        ctx->build.sort_error_dev = nullptr;
+        if (flag) { ctx->have_bvh = false; return fail(ctx, CRT_ERR_HIP, "crt_bvh_build: the key sort's look-back wait gave up"); }
+    }
     return CRT_OK;
 }
 
@@ -516,26 +522,38 @@ int crt_bvh_refit(crt_context *ctx, float *cost) {
     return CRT_OK;
 }
 
-int crt_debug_sort_u64(crt_context *ctx, uint64_t *keys, uint32_t n, uint32_t bit_lo, uint32_t bit_hi) {
+static int debug_sort(crt_context *ctx, const char *what, uint64_t *keys, uint32_t *vals, uint32_t n, uint32_t bit_lo, uint32_t bit_hi) {
     int rc = bind(ctx); if (rc) return rc;
-    if (n && !keys) return fail(ctx, CRT_ERR_INVALID, "crt_debug_sort_u64: null keys");
-    if (bit_lo > bit_hi || bit_hi > 64) return fail(ctx, CRT_ERR_INVALID, "crt_debug_sort_u64: bit range");
+    if (n && (!keys)) return fail(ctx, CRT_ERR_INVALID, std::string(what) + ": null keys");
+    if (bit_lo > bit_hi || bit_hi > 64) return fail(ctx, CRT_ERR_INVALID, std::string(what) + ": bit range");
     if (n == 0) return CRT_OK;
-    DeviceBuffer a, b, scratch;
+    DeviceBuffer a, b, va, vb, scratch;
     std::string err;
     rc = alloc(ctx, a, (size_t)n * 8); if (!rc) rc = alloc(ctx, b, (size_t)n * 8); if (!rc) rc = alloc(ctx, scratch, radix_sort_scratch_bytes(n));
-    const uint64_t *sorted = nullptr; const uint32_t *ew = nullptr;
+    if (!rc && vals) { rc = alloc(ctx, va, (size_t)n * 4); if (!rc) rc = alloc(ctx, vb, (size_t)n * 4); }
+    const uint64_t *sorted = nullptr; const uint32_t *sorted_vals = nullptr, *ew = nullptr;
     uint32_t flag = 0;
     bool ok = false;
     if (!rc && hipMemcpy(a.ptr, keys, (size_t)n * 8, hipMemcpyHostToDevice) == hipSuccess &&
-        radix_sort_keys_u64(ctx->stream, (uint64_t *)a.ptr, (uint64_t *)b.ptr, n, bit_lo, bit_hi, scratch.ptr, &sorted, &ew, err) &&
+        (!vals || hipMemcpy(va.ptr, vals, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess) &&
+        radix_sort_u64(ctx->stream, (uint64_t *)a.ptr, (uint64_t *)b.ptr, (uint32_t *)va.ptr, (uint32_t *)vb.ptr, n, bit_lo, bit_hi, scratch.ptr, &sorted, &sorted_vals, &ew, err) &&
         hipStreamSynchronize(ctx->stream) == hipSuccess && hipMemcpy(keys, sorted, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+        (!vals || hipMemcpy(vals, sorted_vals, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess) &&
         (!ew || hipMemcpy(&flag, ew, 4, hipMemcpyDeviceToHost) == hipSuccess)) ok = true;
-    release(a); release(b); release(scratch);
+    release(a); release(b); release(va); release(vb); release(scratch);
     if (rc) return rc;
-    if (!ok) return fail(ctx, CRT_ERR_HIP, "crt_debug_sort_u64: " + (err.empty() ? std::string("HIP call failed") : err));
-    if (flag) return fail(ctx, CRT_ERR_HIP, "crt_debug_sort_u64: a look-back wait gave up");
+    if (!ok) return fail(ctx, CRT_ERR_HIP, std::string(what) + ": " + (err.empty() ? std::string("HIP call failed") : err));
+    if (flag) return fail(ctx, CRT_ERR_HIP, std::string(what) + ": a look-back wait gave up");
     return CRT_OK;
+}
+
+int crt_debug_sort_u64(crt_context *ctx, uint64_t *keys, uint32_t n, uint32_t bit_lo, uint32_t bit_hi) {
+    return debug_sort(ctx, "crt_debug_sort_u64", keys, nullptr, n, bit_lo, bit_hi);
+}
+
+int crt_debug_sort_pairs_u64(crt_context *ctx, uint64_t *keys, uint32_t *vals, uint32_t n, uint32_t bit_lo, uint32_t bit_hi) {
+    if (n && !vals) return fail(ctx, CRT_ERR_INVALID, "crt_debug_sort_pairs_u64: null values");
+    return debug_sort(ctx, "crt_debug_sort_pairs_u64", keys, vals, n, bit_lo, bit_hi);
 }
 
 int crt_retune(crt_context *ctx) {

@@ -250,6 +250,8 @@ int crt_bvh_wide_read(crt_context *ctx, void *nodes, uint32_t *n_nodes, uint32_t
  * (bvh_sort.hip; stable, so keys that agree on those bits keep their order) and copies them back.  For the sort's unit
  * test; no counterpart in the reference (std::sort inside its builder, bounding_volume_hierarchy.cpp:26-61). */
 int crt_debug_sort_u64(crt_context *ctx, uint64_t *keys, uint32_t n, uint32_t bit_lo, uint32_t bit_hi);
+/* The same with a 32-bit value travelling along with every key (the form static builds of up to a million primitives use). */
+int crt_debug_sort_pairs_u64(crt_context *ctx, uint64_t *keys, uint32_t *vals, uint32_t n, uint32_t bit_lo, uint32_t bit_hi);
 
 /* The AABB-outline debug view (camera.shouldRenderAABB, compute.comp:427-436) draws the boxes of the REFERENCE's
  * BVHNode array (set 0 binding 2, vk_engine.cpp:1203), which the device-side build does not produce.  A caller that

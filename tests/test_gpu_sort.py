@@ -1,7 +1,7 @@
 """The build's own radix sort (bvh_sort.hip, crt_debug_sort_u64) against numpy on Morton-shaped keys: code << idx_bits |
 index with long runs of equal codes, sorted over the code's bits only; stable, so keys with equal codes keep their order
-(= a stable numpy sort by the masked key).  Sizes cross the 4096-key tile, the single-tile case and several thousand
-tiles."""
+(= a stable numpy sort by the masked key).  Sizes cross the tile sizes (1024 keys up to a million keys, 4096 above), the
+single-tile case and several thousand tiles; with and without a value per key."""
 import numpy as np
 import pytest
 
@@ -37,3 +37,17 @@ def test_radix_sort_full_width_and_empty_range():
         assert np.array_equal(ctx.debug_sort_u64(keys, 0, 64), np.sort(keys))
         assert np.array_equal(ctx.debug_sort_u64(keys, 5, 5), keys)          # no bits: nothing moves
         assert np.array_equal(ctx.debug_sort_u64(keys, 60, 64), keys[np.argsort(keys >> np.uint64(60), kind="stable")])
+
+
+@pytest.mark.parametrize("n,code_bits,runs", [(1, 63, 0), (3, 63, 0), (1024, 63, 0), (1025, 63, 9), (224_998, 63, 0), (224_998, 63, 300), (1 << 20, 30, 0), ((1 << 20) + 1, 63, 5)])
+def test_radix_sort_of_pairs_matches_a_stable_numpy_sort(n, code_bits, runs):
+    # the static builds' form: 63-bit Morton codes, the primitive index as the value
+    keys = _keys(n, 0, code_bits, n % 89, runs) >> np.uint64(0)
+    rs = np.random.RandomState(n % 83)
+    keys = (keys & ~np.uint64((1 << 20) - 1)) | (keys & np.uint64((1 << 20) - 1)) >> np.uint64(rs.randint(0, 12))      # equal keys happen
+    vals = rs.permutation(n).astype(np.uint32)
+    with abi.Context(0) as ctx:
+        got_k, got_v = ctx.debug_sort_pairs_u64(keys, vals, 0, code_bits)
+    mask = np.uint64((1 << code_bits) - 1)
+    order = np.argsort(keys & mask, kind="stable")
+    assert np.array_equal(got_k, keys[order]) and np.array_equal(got_v, vals[order])
