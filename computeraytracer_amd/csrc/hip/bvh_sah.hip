@@ -85,7 +85,7 @@ struct SahGroupArgs {
     uint32_t max_leaf; float c_isect, c_trav;
     // fused collapse table (bvh_wide.hip; null: not wanted): eight words per pair (only a group's root row is written: the
     // next tier reads it), one choice word per pair
-    float *dp_cost; unsigned long long *dp_choice;
+    float *dp_cost; unsigned long long *dp_choice; uint32_t n_pairs_total;
 };
 
 struct SahLds {
@@ -482,8 +482,8 @@ __global__ __launch_bounds__(kSahThreads) void k_sah_group(SahGroupArgs g) {
             blo[0] = b0.x; blo[1] = b0.y; blo[2] = b0.z; bhi[0] = b1.x; bhi[1] = b1.y; bhi[2] = b1.z;
             la = __float_as_uint(a0.w); lb = __float_as_uint(b0.w);
             const uint32_t ca = __float_as_uint(a1.w), cb = __float_as_uint(b1.w);
-            if (ca == 0u && la != 0u) { if (la >= pair_base && la - pair_base < np) { ka = 1u; la -= pair_base; } else ka = 2u; }
-            if (cb == 0u && lb != 0u) { if (lb >= pair_base && lb - pair_base < np) { kb = 1u; lb -= pair_base; } else kb = 2u; }
+            if (ca == 0u && la != 0u) { if (la >= pair_base && la - pair_base < np) { ka = 1u; la -= pair_base; } else if (la < g.n_pairs_total) ka = 2u; }
+            if (cb == 0u && lb != 0u) { if (lb >= pair_base && lb - pair_base < np) { kb = 1u; lb -= pair_base; } else if (lb < g.n_pairs_total) kb = 2u; }
         }
         if (tid < kGroup) L.dp_done[tid] = 0;
         __syncthreads();
@@ -598,7 +598,7 @@ bool build_sah(hipStream_t stream, const BuildInput &in, BuildState &st, const u
         g.desc_out = t + 1 == tiers.size() ? nullptr : desc + 2 * tiers[t].starts_off;
         g.pairs = (float4 *)st.pairs.ptr; g.perm = (uint32_t *)st.perm.ptr;
         g.max_leaf = st.max_leaf < 1u ? 1u : st.max_leaf > 8u ? 8u : st.max_leaf; g.c_isect = st.c_isect; g.c_trav = st.c_trav;
-        g.dp_cost = fuse ? (float *)st.dp_cost.ptr : nullptr; g.dp_choice = fuse ? (unsigned long long *)st.dp_choice.ptr : nullptr;
+        g.dp_cost = fuse ? (float *)st.dp_cost.ptr : nullptr; g.dp_choice = fuse ? (unsigned long long *)st.dp_choice.ptr : nullptr; g.n_pairs_total = st.n_pairs;
         hipLaunchKernelGGL(k_sah_group, dim3(g.n_groups), dim3(kSahThreads), 0, stream, g);
     }
     HIP_TRY(hipGetLastError());

@@ -148,7 +148,11 @@ __device__ __forceinline__ void compact8(Child8 &c, uint32_t sl) {
 // Collapses the subtree of pair `src` into node `dst` of level `level`; its inner children are appended to q_out (the queue
 // of level + 1) and numbered next_base + position (next_base = nodes of levels 0 .. level).  Called by whole waves;
 // active, src and dst are uniform over a group of eight lanes, sl = lane & 7.
-__device__ __forceinline__ void wide_emit8(const float4 *pairs, const unsigned long long *choice, uint32_t level, uint32_t *level_count, uint32_t next_base,
+// n_pairs bounds every pair index and every node number: a link that points outside the pair array, or more nodes than
+// pairs, can only come from a corrupt tree; such children are dropped and the error word set (the build fails at its next
+// read-back) instead of the kernel reading or writing out of bounds.
+constexpr uint32_t kWideErrWord = kWideMaxLevels + 4;
+__device__ __forceinline__ void wide_emit8(const float4 *pairs, const unsigned long long *choice, uint32_t n_pairs, uint32_t level, uint32_t *level_count, uint32_t next_base,
                                            bool active, uint32_t src, uint32_t dst, uint2 *q_out, float4 *wide, uint32_t *links) {
     const uint32_t sl = threadIdx.x & 7u;
     Child8 c;
@@ -177,13 +181,13 @@ __device__ __forceinline__ void wide_emit8(const float4 *pairs, const unsigned l
         const uint32_t n = (uint32_t)__builtin_popcount(group_mask8(c.valid));
         bool dis = false; uint32_t grant = 0u;
         if (choice) {
-            if (c.valid && c.count == 0u && c.budget >= 2u) {
+            if (c.valid && c.count == 0u && c.budget >= 2u && c.link < n_pairs) {
                 const uint32_t bud = c.budget > 7u ? 7u : c.budget;
                 const uint32_t eff = (c.eff >> (3u * (bud - 1u))) & 7u;
                 if (eff > 1u) { dis = true; grant = eff; } else c.budget = 1u;      // stays a wide node of its own
             }
         } else {
-            const float area = (c.valid && c.count == 0u) ? half_area3(c.lo, c.hi) : -1.0f;
+            const float area = (c.valid && c.count == 0u && c.link < n_pairs) ? half_area3(c.lo, c.hi) : -1.0f;
             float best = area > -1.0f ? area : -1.0f; uint32_t who = area > -1.0f ? sl : 8u;      // (a NaN area is never chosen)
 #pragma unroll
             for (int off = 1; off < 8; off <<= 1) {
@@ -259,11 +263,17 @@ __device__ __forceinline__ void wide_emit8(const float4 *pairs, const unsigned l
     for (int j = 0; j < 8; j++) { const uint32_t sj = (uint32_t)__shfl((int)my_slot, j, 8); from = sj == sl ? (uint32_t)j : from; }
     pull8(c, from & 7u, true);
     c.valid = c.valid && from < 8u;
-    const uint32_t imask = group_mask8(c.valid && c.count == 0u);
-    const uint32_t n_inner = (uint32_t)__builtin_popcount(imask);
+    if (c.valid && c.count == 0u && c.link >= n_pairs) { c.valid = false; atomicOr(&level_count[kWideErrWord], 1u); }
+    uint32_t imask = group_mask8(c.valid && c.count == 0u);
+    uint32_t n_inner = (uint32_t)__builtin_popcount(imask);
     uint32_t qpos = 0u;
     if (active && sl == 0u && n_inner) qpos = atomicAdd(&level_count[level + 1], n_inner);
     qpos = (uint32_t)__shfl((int)qpos, 0, 8);
+    if (n_inner && (uint64_t)next_base + qpos + n_inner > (uint64_t)n_pairs) {      // more nodes than pairs: not a tree
+        if (active && sl == 0u) atomicOr(&level_count[kWideErrWord], 2u);
+        if (c.count == 0u) c.valid = false;
+        imask = 0u; n_inner = 0u;
+    }
     const uint32_t child_base = next_base + qpos;
     uint32_t lk = kWideEmptyLink;
     if (c.valid) {
@@ -283,18 +293,19 @@ __device__ __forceinline__ void wide_emit8(const float4 *pairs, const unsigned l
 // level_count[l] = wide nodes of level l (queue length); level l reads queue l & 1 and appends to the other one.
 // Levels below *first_level were already emitted by k_wide_top.  Eight lanes per node.
 constexpr uint32_t kWideLevelThreads = 256;
-__global__ __launch_bounds__(kWideLevelThreads) void k_wide_level(const float4 *pairs, const unsigned long long *choice, uint32_t level, uint32_t *level_count,
+__global__ __launch_bounds__(kWideLevelThreads) void k_wide_level(const float4 *pairs, const unsigned long long *choice, uint32_t n_pairs, uint32_t level, uint32_t *level_count,
                                                                   const uint32_t *first_level, const uint2 *q_in, uint2 *q_out, float4 *wide, uint32_t *links) {
     if (level < *first_level) return;
-    const uint32_t n_in = level_count[level];
+    const uint32_t n_in = min(level_count[level], n_pairs);
     uint32_t next_base = 0;                         // nodes of levels 0..level = index of the first node of level + 1
     for (uint32_t l = 0; l <= level; l++) next_base += level_count[l];
     const uint32_t stride = (gridDim.x * blockDim.x) >> 3;
     for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;; i += stride) {
-        const bool active = i < n_in;
+        bool active = i < n_in;
         if (__ballot(active) == 0ull) break;
         const uint2 w = active ? q_in[i] : make_uint2(0u, 0u);
-        wide_emit8(pairs, choice, level, level_count, next_base, active, w.x, w.y, q_out, wide, links);
+        if (w.x >= n_pairs || w.y >= n_pairs) active = false;      // (an entry nobody wrote: only after the error word was set)
+        wide_emit8(pairs, choice, n_pairs, level, level_count, next_base, active, w.x, w.y, q_out, wide, links);
     }
 }
 
@@ -303,10 +314,11 @@ __global__ __launch_bounds__(kWideLevelThreads) void k_wide_level(const float4 *
 // level it did not do in *first_level (k_wide_level skips the earlier ones).  Everything it hands from one level to the
 // next (queue entries, level counts) stays inside the workgroup: workgroup-scope release / acquire around the barrier.
 constexpr uint32_t kWideTopThreads = 1024;
-__global__ __launch_bounds__(kWideTopThreads) void k_wide_top(const float4 *pairs, const unsigned long long *choice, uint32_t *level_count, uint32_t max_levels,
+__global__ __launch_bounds__(kWideTopThreads) void k_wide_top(const float4 *pairs, const unsigned long long *choice, uint32_t n_pairs, uint32_t *level_count, uint32_t max_levels,
                                                               uint32_t *first_level, uint2 *q0, uint2 *q1, float4 *wide, uint32_t *links, const float *root_row) {
     // (the pair tree's height, which the fused table left in word 7 of the root's row, rides to the host with the level table)
-    if (threadIdx.x == 0 && root_row) level_count[kWideMaxLevels + 3] = __float_as_uint(root_row[7]);
+    if (threadIdx.x == 0) { level_count[kWideMaxLevels + 3] = root_row ? __float_as_uint(root_row[7]) : 0u; level_count[kWideErrWord] = 0u; }
+    __syncthreads();
     uint32_t next_base = 0, level = 0;
     for (; level < max_levels; level++) {
         const uint32_t n_in = __hip_atomic_load(&level_count[level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -315,10 +327,11 @@ __global__ __launch_bounds__(kWideTopThreads) void k_wide_top(const float4 *pair
         const uint2 *q_in = (level & 1u) ? q1 : q0;
         uint2 *q_out = (level & 1u) ? q0 : q1;
         const uint32_t i = threadIdx.x >> 3;
-        const bool active = i < n_in;
+        bool active = i < n_in;
         if (__ballot(active) != 0ull) {
             const uint2 w = active ? q_in[i] : make_uint2(0u, 0u);
-            wide_emit8(pairs, choice, level, level_count, next_base, active, w.x, w.y, q_out, wide, links);
+            if (w.x >= n_pairs || w.y >= n_pairs) active = false;
+            wide_emit8(pairs, choice, n_pairs, level, level_count, next_base, active, w.x, w.y, q_out, wide, links);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
@@ -357,7 +370,7 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
     st.wide_cap = st.n_pairs;
     uint32_t *links = (uint32_t *)((float4 *)st.wide.ptr + (size_t)kWideStrideF4 * st.wide_cap);
     if (!ensure_w(st.wide_queue[0], (size_t)st.n_pairs * 8, err) || !ensure_w(st.wide_queue[1], (size_t)st.n_pairs * 8, err)) return false;
-    if (!ensure_w(st.wide_levels_dev, (kWideMaxLevels + 4) * 4, err)) return false;
+    if (!ensure_w(st.wide_levels_dev, (kWideMaxLevels + 5) * 4, err)) return false;
     uint32_t *lc = (uint32_t *)st.wide_levels_dev.ptr;
     // ---- the table (only when the pairs' depths were measured, i.e. after the SAH refinement: the per-frame LBVH rebuild
     // keeps the cheaper greedy rule): buckets by depth -> one launch per depth, deepest first ------------------------------
@@ -379,11 +392,11 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
     }
     hipLaunchKernelGGL(k_wide_init, dim3(1), dim3(128), 0, stream, lc, kWideMaxLevels + 1, (uint2 *)st.wide_queue[0].ptr);
     uint32_t *first_level = lc + kWideMaxLevels + 2;
-    hipLaunchKernelGGL(k_wide_top, dim3(1), dim3(kWideTopThreads), 0, stream, (const float4 *)st.pairs.ptr, choice, lc, kWideMaxLevels, first_level,
+    hipLaunchKernelGGL(k_wide_top, dim3(1), dim3(kWideTopThreads), 0, stream, (const float4 *)st.pairs.ptr, choice, st.n_pairs, lc, kWideMaxLevels, first_level,
                        (uint2 *)st.wide_queue[0].ptr, (uint2 *)st.wide_queue[1].ptr, (float4 *)st.wide.ptr, links,
                        st.dp_fused ? (const float *)st.dp_cost.ptr : (const float *)nullptr);
     const uint32_t grid = std::min<uint32_t>(2048u, (st.n_pairs * 8u + kWideLevelThreads - 1u) / kWideLevelThreads);
-    uint32_t host_lc[kWideMaxLevels + 4];
+    uint32_t host_lc[kWideMaxLevels + 5];
     bool height_read = false;
     uint32_t level = 3;      // k_wide_top always does levels 0, 1 and 2 (1, <= 8, <= 64 nodes; a launch that finds its level done still costs ~4.5 us)
     // launches are planned blind, a chunk of levels at a time; the first chunk is as long as the previous build's tree was
@@ -392,12 +405,13 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
     for (;; chunk = 4u) {
         const uint32_t chunk_end = std::min<uint32_t>(level + chunk, kWideMaxLevels);
         for (; level < chunk_end; level++)
-            hipLaunchKernelGGL(k_wide_level, dim3(grid), dim3(kWideLevelThreads), 0, stream, (const float4 *)st.pairs.ptr, choice, level, lc, (const uint32_t *)first_level,
+            hipLaunchKernelGGL(k_wide_level, dim3(grid), dim3(kWideLevelThreads), 0, stream, (const float4 *)st.pairs.ptr, choice, st.n_pairs, level, lc, (const uint32_t *)first_level,
                                (const uint2 *)st.wide_queue[level & 1].ptr, (uint2 *)st.wide_queue[(level & 1) ^ 1].ptr,
                                (float4 *)st.wide.ptr, links);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(host_lc, lc, (kWideMaxLevels + 4) * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(host_lc, lc, (kWideMaxLevels + 5) * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        if (host_lc[kWideErrWord]) { err = "the pair tree is not a tree (a link outside the pair array, or more wide nodes than pairs)"; return false; }
         if (st.dp_fused && !height_read) {      // the pair tree's height came with the table (bvh_sah.hip): the pair tracers' stacks bound it
             height_read = true;
             st.pair_depth = host_lc[kWideMaxLevels + 3] >> 21;
