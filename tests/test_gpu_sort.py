@@ -2,6 +2,10 @@
 index with long runs of equal codes, sorted over the code's bits only; stable, so keys with equal codes keep their order
 (= a stable numpy sort by the masked key).  Sizes cross the tile sizes (1024 keys up to a million keys, 4096 above), the
 single-tile case and several thousand tiles; with and without a value per key."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -51,3 +55,17 @@ def test_radix_sort_of_pairs_matches_a_stable_numpy_sort(n, code_bits, runs):
     mask = np.uint64((1 << code_bits) - 1)
     order = np.argsort(keys & mask, kind="stable")
     assert np.array_equal(got_k, keys[order]) and np.array_equal(got_v, vals[order])
+
+
+@pytest.mark.parametrize("name", ["voxel_city", "cirno"])
+def test_static_build_through_the_own_sort_gives_the_same_tree(name):
+    # CRT_BVH_SORT=onesweep sends the (Morton code, primitive) pairs of a static build through bvh_sort.hip instead of rocPRIM;
+    # both sorts are stable, so the order, the tree and the image are the same.  The variable is read once per process.
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = []
+    for sort in ("rocprim", "onesweep"):
+        env = dict(os.environ, CRT_BVH_SORT=sort, PYTHONPATH=os.pathsep.join([os.path.dirname(here), here, os.environ.get("PYTHONPATH", "")]))
+        r = subprocess.run([sys.executable, os.path.join(here, "sort_build_check.py"), name], env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        out.append([l for l in r.stdout.splitlines() if l.startswith("tree ")][-1])
+    assert out[0] == out[1] and int(out[0].split()[1]) > 0
