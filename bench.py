@@ -55,7 +55,7 @@ def requested_gpus(argv):
 
 
 PHASES = ("start", "dist_init", "scene_upload", "bvh_build", "instrumented_step", "warmup", "timed_steps", "reduce",
-          "comm_init", "first_gather", "timed_gather", "gather_check", "report", "done")
+          "comm_init", "first_gather", "timed_gather", "fallback_gather", "gather_check", "report", "done")
 
 
 class Phase:
@@ -63,6 +63,7 @@ class Phase:
     self-launcher started the rank, in a one-line file the launcher reads (CRT_BENCH_PHASE_DIR/rank_<r>)."""
     def __init__(self, rank):
         self.rank, self.name, self.t0 = rank, "start", time.time()
+        self.pending = None      # rank 0: the finished result line while the (untimed) image gather is still running
         d = os.environ.get("CRT_BENCH_PHASE_DIR", "")
         self.path = os.path.join(d, f"rank_{rank}") if d else None
         self.set("start")
@@ -92,6 +93,12 @@ def start_watchdog(phase, world, seconds):
             time.sleep(0.25)
         if phase.name == "done":
             return
+        pending = phase.pending
+        if pending is not None:      # the measurement is complete, only the gather of the image is stuck: report it as what it is
+            pending["config"]["gather"] = f"failed: timeout in phase {phase.name} after {round(time.time() - phase.t0, 1)} s"
+            pending["config"]["gather_ms"], pending["config"]["gather_check"] = None, None
+            print(json.dumps(pending), flush=True)
+            os._exit(0)
         print(json.dumps({"error": "timeout", "rank": phase.rank, "n_gpus": world, "phase": phase.name,
                           "after_s": round(time.time() - phase.t0, 1)}), flush=True)
         os._exit(3)
@@ -472,6 +479,10 @@ def main():
         per = per.cpu().numpy().reshape(world, 2)
         rank_ms = [float(x) / args.steps * 1e3 for x in per[:, 0]]
         per_rank_rays = [float(x) for x in per[:, 1]]
+    def gather_phase():
+        import torch
+        tdev = torch.device("cpu") if rehearse else torch.device("cuda", local_rank)
+        gather_ms, gather_check = None, None
         # gather the finished image: ONE all-gather of the packed band buffers + un-interleave, outside `value`
         gather_path = "rccl-native"
         if rehearse:
@@ -488,22 +499,52 @@ def main():
             full = image.cpu().numpy()
         else:
             # the product path: crt_comm_init + crt_image_gather inside libcrt.so (csrc/dist/gather_rccl.hip); torch.distributed
-            # only carries the 128-byte communicator id from rank 0 to the others
+            # only carries the 128-byte communicator id from rank 0 to the others.  The gather is outside `value`, so a
+            # communicator that cannot be made must not cost the run its result: every step that can raise is followed by an
+            # agreement (all-reduce MIN of "ok") before anybody enters the next collective, and if the native path is not
+            # available on every rank the image is gathered through torch.distributed instead and the line says so.
+            def agree(ok):
+                f = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=tdev)
+                dist.all_reduce(f, op=dist.ReduceOp.MIN)
+                return float(f[0]) == 1.0
+            native_error = None
             phase.set("comm_init")
             idt = torch.zeros(abi.COMM_ID_BYTES, dtype=torch.uint8, device=tdev)
+            ok = True
             if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(abi.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, 0)
-            ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
-            phase.set("first_gather")
-            ctx.image_gather(); ctx.sync()            # the first collective on a communicator sets its channels up: untimed
-            torch.cuda.synchronize(); dist.barrier()
-            phase.set("timed_gather")
-            g0 = time.perf_counter()
-            ctx.image_gather(); ctx.sync()
-            gather_ms = (time.perf_counter() - g0) * 1e3
-            full = ctx.image_gathered()
-            ctx.comm_destroy()
+                try:
+                    idt.copy_(torch.frombuffer(bytearray(abi.comm_unique_id()), dtype=torch.uint8))
+                except Exception as e:      # noqa: BLE001 -- reported in the line
+                    ok, native_error = False, f"crt_comm_unique_id: {e}"
+            ok = agree(ok)
+            if ok:
+                dist.broadcast(idt, 0)
+                try:
+                    ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+                except Exception as e:      # noqa: BLE001
+                    ok, native_error = False, f"crt_comm_init: {e}"
+                ok = agree(ok)
+            if ok:
+                phase.set("first_gather")
+                ctx.image_gather(); ctx.sync()            # the first collective on a communicator sets its channels up: untimed
+                torch.cuda.synchronize(); dist.barrier()
+                phase.set("timed_gather")
+                g0 = time.perf_counter()
+                ctx.image_gather(); ctx.sync()
+                gather_ms = (time.perf_counter() - g0) * 1e3
+                full = ctx.image_gathered()
+                ctx.comm_destroy()
+            else:
+                phase.set("fallback_gather")
+                gather_path = "torch-nccl-fallback (native communicator unavailable" + (": " + native_error if native_error else " on another rank") + ")"
+                from computeraytracer_amd import dist as cdist
+                band = cdist.context_band_tensor(ctx, W, torch.device("cuda", local_rank))
+                torch.cuda.synchronize(); dist.barrier()
+                g0 = time.perf_counter()
+                image = cdist.gather_image(band, H, world)
+                torch.cuda.synchronize()
+                gather_ms = (time.perf_counter() - g0) * 1e3
+                full = image.cpu().numpy()
         # every rank's bands arrived: each pixel of the rendered grid carries the last iteration's number in .w, and
         # this rank's own rows are the ones it rendered
         phase.set("gather_check")
@@ -517,6 +558,8 @@ def main():
         gt = torch.tensor([gather_ms], dtype=torch.float64, device=tdev)
         dist.all_reduce(gt, op=dist.ReduceOp.MAX)
         gather_ms = float(gt[0])
+
+        return gather_ms, gather_path, gather_check
 
     phase.set("report")
     if rank == 0:
@@ -611,6 +654,26 @@ def main():
                                                   "all": [round(x, 4) for x in rank_ms]}
             line["config"]["rank_rays_share"] = {"min": round(min(per_rank_rays) / max(sum(per_rank_rays), 1.0), 5),
                                                  "max": round(max(per_rank_rays) / max(sum(per_rank_rays), 1.0), 5)}
+    if dist is not None:
+        # The gather comes last and is outside `value`: rank 0's line is complete by now, and the watchdog prints it (with
+        # the gather marked as failed) if a rank gets stuck in the communicator set-up or in the collective.
+        if rank == 0:
+            phase.pending = line
+        try:
+            gather_ms, gather_path, gather_check = gather_phase()
+        except Exception as e:      # noqa: BLE001 -- the result must not be lost to the untimed gather
+            if rank == 0:
+                line["config"]["gather"] = f"failed in phase {phase.name}: {e}"
+                line["config"]["gather_ms"], line["config"]["gather_check"] = None, None
+                print(json.dumps(line), flush=True)
+                os._exit(0)         # the other ranks may be inside a collective that will never complete
+            raise
+        if rank == 0:
+            phase.pending = None
+            line["config"]["gather_ms"] = None if gather_ms is None else round(gather_ms, 3)
+            line["config"]["gather"] = gather_path
+            line["config"]["gather_check"] = gather_check
+    if rank == 0:
         print(json.dumps(line), flush=True)
     ctx.close()
     if dist is not None:

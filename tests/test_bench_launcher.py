@@ -115,3 +115,25 @@ def test_rank_watchdog_prints_rank_and_phase_then_exits(tmp_path):
     assert r.returncode == 3
     lines = _json_lines(r.stdout)
     assert len(lines) == 1 and lines[0]["error"] == "timeout" and lines[0]["rank"] == 5 and lines[0]["phase"] == "first_gather" and lines[0]["n_gpus"] == 8
+
+
+def test_rank_watchdog_prints_the_finished_line_when_only_the_gather_hangs(tmp_path):
+    # the image gather is untimed and comes after the measurement: a communicator that hangs must not cost the run its
+    # result.  Rank 0 hands its finished line to the watchdog before it enters the gather.
+    import subprocess
+    code = (
+        "import os, sys, time\n"
+        "sys.argv = ['bench.py']\n"
+        "import importlib.util\n"
+        "spec = importlib.util.spec_from_file_location('crt_bench', %r)\n"
+        "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+        "ph = m.Phase(0); m.start_watchdog(ph, 8, 1.0)\n"
+        "ph.pending = {'metric': 'x', 'value': 123.0, 'n_gpus': 8, 'config': {'gather': None, 'gather_ms': 1.0, 'gather_check': 'ok'}}\n"
+        "ph.set('comm_init')\n"
+        "time.sleep(30)\n" % os.path.join(ROOT, "bench.py"))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 0
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["value"] == 123.0 and "error" not in lines[0]
+    assert lines[0]["config"]["gather"].startswith("failed: timeout in phase comm_init") and lines[0]["config"]["gather_check"] is None
