@@ -287,6 +287,10 @@ __device__ __forceinline__ void wide_emit8(const float4 *pairs, const unsigned l
         }
     }
     if (active) links[8 * (size_t)dst + sl] = lk;
+    if (!c.valid) {      // empty slots take no part in the node's box (wide_node_finish reduces over all eight lanes)
+#pragma unroll
+        for (int a = 0; a < 3; a++) { c.lo[a] = 3.402823466e38f; c.hi[a] = -3.402823466e38f; }
+    }
     wide_node_finish(active, sl, dst, (child_base << 8) | imask, c.lo, c.hi, c.valid, wide, nullptr, nullptr);
 }
 
