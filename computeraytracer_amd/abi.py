@@ -101,6 +101,7 @@ def _load():
         "crt_retune": (i32, [vp]),
         "crt_debug_sort_u64": (i32, [vp, vp, u32, u32, u32]),
         "crt_debug_sort_pairs_u64": (i32, [vp, vp, vp, u32, u32, u32]),
+        "crt_debug_math": (i32, [vp, i32, u32, vp, vp, vp, vp]),
         "crt_tris_update": (i32, [vp, vp, u32, u32]),
         "crt_tris_animate": (i32, [vp, f32, f32]),
         "crt_tris_read": (i32, [vp, vp, u32, u32]),
@@ -380,6 +381,14 @@ class Context:
         v = np.ascontiguousarray(vals, dtype=np.uint32).copy()
         self._check(lib.crt_debug_sort_pairs_u64(self._h, _ptr(k), _ptr(v), len(k), bit_lo, bit_hi), "crt_debug_sort_pairs_u64")
         return k, v
+
+    def debug_math(self, fn, a, b=None):
+        """crt_debug_math: (out0, out1) of function `fn` on the device for float32 arrays a (and b)."""
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b if b is not None else np.zeros_like(a), dtype=np.float32)
+        o0, o1 = np.zeros_like(a), np.zeros_like(a)
+        self._check(lib.crt_debug_math(self._h, fn, a.size, _ptr(a), _ptr(b), _ptr(o0), _ptr(o1)), "crt_debug_math")
+        return o0, o1
 
     def retune(self):
         self._check(lib.crt_retune(self._h), "crt_retune")

@@ -12,7 +12,10 @@
 #include "gather_internal.h"
 #include "crt/abi.h"
 
-namespace crt { void set_host_error(const std::string &msg); }      // host/host.cpp: the thread-local message behind crt_host_last_error()
+namespace crt {
+void set_host_error(const std::string &msg);
+bool debug_math(hipStream_t stream, int fn, uint32_t n, const float *a, const float *b, float *out0, float *out1, std::string &err);      // debug_math.hip
+}      // host/host.cpp: the thread-local message behind crt_host_last_error()
 
 using namespace crt;
 
@@ -554,6 +557,25 @@ int crt_debug_sort_u64(crt_context *ctx, uint64_t *keys, uint32_t n, uint32_t bi
 int crt_debug_sort_pairs_u64(crt_context *ctx, uint64_t *keys, uint32_t *vals, uint32_t n, uint32_t bit_lo, uint32_t bit_hi) {
     if (n && !vals) return fail(ctx, CRT_ERR_INVALID, "crt_debug_sort_pairs_u64: null values");
     return debug_sort(ctx, "crt_debug_sort_pairs_u64", keys, vals, n, bit_lo, bit_hi);
+}
+
+int crt_debug_math(crt_context *ctx, int fn, uint32_t n, const float *a, const float *b, float *out0, float *out1) {
+    int rc = bind(ctx); if (rc) return rc;
+    if (n && (!a || !b || !out0 || !out1)) return fail(ctx, CRT_ERR_INVALID, "crt_debug_math: null array");
+    if (n == 0) return CRT_OK;
+    DeviceBuffer da, db, d0, d1;
+    const size_t bytes = (size_t)n * 4;
+    rc = alloc(ctx, da, bytes); if (!rc) rc = alloc(ctx, db, bytes); if (!rc) rc = alloc(ctx, d0, bytes); if (!rc) rc = alloc(ctx, d1, bytes);
+    std::string err;
+    bool ok = false;
+    if (!rc && hipMemcpy(da.ptr, a, bytes, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(db.ptr, b, bytes, hipMemcpyHostToDevice) == hipSuccess &&
+        debug_math(ctx->stream, fn, n, (const float *)da.ptr, (const float *)db.ptr, (float *)d0.ptr, (float *)d1.ptr, err) &&
+        hipStreamSynchronize(ctx->stream) == hipSuccess && hipMemcpy(out0, d0.ptr, bytes, hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(out1, d1.ptr, bytes, hipMemcpyDeviceToHost) == hipSuccess) ok = true;
+    release(da); release(db); release(d0); release(d1);
+    if (rc) return rc;
+    if (!ok) return fail(ctx, CRT_ERR_HIP, "crt_debug_math: " + (err.empty() ? std::string("HIP call failed") : err));
+    return CRT_OK;
 }
 
 int crt_retune(crt_context *ctx) {

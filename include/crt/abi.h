@@ -250,6 +250,11 @@ int crt_bvh_wide_read(crt_context *ctx, void *nodes, uint32_t *n_nodes, uint32_t
  * (bvh_sort.hip; stable, so keys that agree on those bits keep their order) and copies them back.  For the sort's unit
  * test; no counterpart in the reference (std::sort inside its builder, bounding_volume_hierarchy.cpp:26-61). */
 int crt_debug_sort_u64(crt_context *ctx, uint64_t *keys, uint32_t n, uint32_t bit_lo, uint32_t bit_hi);
+/* Build-only diagnostic: the build-defined FP32 sequences of the device (sin/cos on [0, 2 pi], cube root on [0, 1], acos,
+ * atan2, x^5) and its IEEE square root and division, evaluated on the GPU for n host-side arguments.  fn: 0 sincos
+ * (out0 = sin, out1 = cos), 1 cbrt01, 2 acos, 3 atan2(a, b), 4 pow5, 5 sqrt, 6 a / b.  No counterpart in the reference
+ * (GLSL leaves these to the driver); lets a test compare the device with the oracle function by function. */
+int crt_debug_math(crt_context *ctx, int fn, uint32_t n, const float *a, const float *b, float *out0, float *out1);
 /* The same with a 32-bit value travelling along with every key (the form static builds of up to a million primitives use). */
 int crt_debug_sort_pairs_u64(crt_context *ctx, uint64_t *keys, uint32_t *vals, uint32_t n, uint32_t bit_lo, uint32_t bit_hi);
 
