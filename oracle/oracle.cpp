@@ -581,6 +581,17 @@ struct FastBVH {
 void fast_bounds(const Scene &sc, uint32_t id, double lo[3], double hi[3]) {
     AABB b = prim_box(sc, id);
     double m[3] = {b.mn.x, b.mn.y, b.mn.z}, M[3] = {b.mx.x, b.mx.y, b.mx.z};
+    if ((id >> 30) == KIND_QUAD) {
+        // The reference's quad box spans two opposite corners only (primitives.h:82-84: AABB(corner, corner + u + v)),
+        // which leaves the other two corners of a parallelogram outside unless u and v run along the axes (they do in
+        // every reference scene).  Its threaded BVH (ORC_TRAVERSE_REF) therefore clips such a quad to that box; the
+        // canonical semantics are those of brute force, so this tree bounds all four corners.
+        const Quad &q = sc.quads[id & 0x3FFFFFFFu];
+        for (int a = 0; a < 3; a++) {
+            const double c = q.corner[a], cu = c + (double)q.u[a], cv = c + (double)q.v[a], cuv = c + (double)q.u[a] + (double)q.v[a];
+            m[a] = std::min(std::min(c, cu), std::min(cv, cuv)); M[a] = std::max(std::max(c, cu), std::max(cv, cuv));
+        }
+    }
     for (int a = 0; a < 3; a++) {
         double padv = 1e-5 * (fabs(m[a]) + fabs(M[a]) + (M[a] - m[a])) + 1e-7;
         lo[a] = m[a] - padv; hi[a] = M[a] + padv;

@@ -1,0 +1,44 @@
+"""Random scenes for tests/test_gpu_fuzz.py (GPU against the oracle) and tests/test_oracle_bvh.py (the oracle's tree against
+its brute force): every primitive kind, every material kind, a texture, lens blur, either background mode."""
+import numpy as np
+
+from computeraytracer_amd import abi
+
+
+def random_scene(seed, w, h):
+    rs = np.random.RandomState(1000 + seed)
+    n_mat = 7
+    mats = np.zeros(n_mat, abi.material_dtype)
+    mats["albedo"] = rs.uniform(0.05, 0.95, (n_mat, 3)).astype(np.float32)
+    mats["type"] = rs.choice([abi.MAT_LAMBERTIAN, abi.MAT_METAL, abi.MAT_DIELECTRIC, abi.MAT_DIFFUSE_LIGHT], n_mat, p=[0.45, 0.25, 0.15, 0.15])
+    mats["type"][0] = abi.MAT_LAMBERTIAN
+    mats["fuzziness"] = np.where(mats["type"] == abi.MAT_DIELECTRIC, rs.uniform(1.1, 2.4, n_mat), rs.uniform(0.0, 0.6, n_mat)).astype(np.float32)
+    mats["albedo"][mats["type"] == abi.MAT_DIFFUSE_LIGHT] *= np.float32(8.0)
+    mats["textureIndex"] = 0xFFFFFFFF
+    mats["textureIndex"][0] = 0                                   # one textured Lambertian
+    tex = rs.randint(0, 256, (8, 16, 4)).astype(np.uint8)
+    n_s, n_q, n_t = [int(rs.randint(0, m)) for m in (30, 12, 400)]
+    if seed % 3 == 0:
+        n_t += 300                                                # more than one SAH group now and then
+    spheres = np.zeros(n_s, abi.sphere_dtype)
+    spheres["center"] = rs.uniform(-4, 4, (n_s, 3)).astype(np.float32) * np.float32([1, 0.4, 1])
+    spheres["radius"] = (rs.uniform(0.1, 0.9, n_s) * rs.choice([1.0, 1.0, 1.0, -1.0], n_s)).astype(np.float32)      # negative: the normal flips (vk_engine.cpp:853)
+    spheres["materialIndex"] = rs.randint(0, n_mat, n_s)
+    quads = np.zeros(n_q, abi.quad_dtype)
+    for i in range(n_q):
+        quads[i] = abi.make_quad(rs.uniform(-4, 4, 3), rs.uniform(-1.5, 1.5, 3), rs.uniform(-1.5, 1.5, 3), int(rs.randint(0, n_mat)))[0]
+    tris = np.zeros(n_t, abi.tri_dtype)
+    c = rs.uniform(-4, 4, (n_t, 3)).astype(np.float32) * np.float32([1, 0.5, 1])
+    e = rs.uniform(-0.7, 0.7, (2, n_t, 3)).astype(np.float32)
+    tris["v0"], tris["v1"], tris["v2"] = c, c + e[0], c + e[1]
+    tris["u"] = rs.uniform(-1, 2, (n_t, 3)).astype(np.float32); tris["v"] = rs.uniform(-1, 2, (n_t, 3)).astype(np.float32)
+    tris["materialIndex"] = rs.randint(0, n_mat, n_t)
+    if n_t > 20:
+        tris["v2"][:5] = tris["v1"][:5]                           # a few degenerate ones
+    params = np.zeros(1, abi.params_dtype)
+    params["backgroundColor"] = (-1.0, -1.0, -1.0) if seed % 2 == 0 else tuple(rs.uniform(0, 0.4, 3))      # sky gradient / flat colour
+    pos = rs.uniform(-6, 6, 3) * np.float32([1, 0.3, 1]) + np.float32([0, 1.0, 0])
+    if seed == 5 and n_s:
+        pos = spheres["center"][0] + np.float32([0.01, 0.02, 0.0])                                        # the camera inside a sphere
+    params["camera"] = abi.camera(tuple(pos), tuple(rs.uniform(-1, 1, 3)), float(rs.uniform(30, 80)), w / h, float(rs.choice([0.0, 1.0 / 45.0, 0.2])), float(rs.uniform(3, 9)))
+    return abi.HostScene(spheres=spheres, quads=quads, tris=tris, materials=mats, textures=[tex], params=params, name=f"fuzz-{seed}")

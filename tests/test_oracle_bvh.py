@@ -122,3 +122,18 @@ def test_libm_mode_is_close_to_fixed_sequences():
     b, _, _ = orc.render(sc, ps, 96, 54, flags=orc.TRAVERSE_FAST | orc.LIBM, max_bounces=1)
     rmse = np.sqrt(np.mean((a[..., :3] - b[..., :3]) ** 2))
     assert rmse <= 1e-5   # SURVEY 8(d) depth-1 tolerance
+
+
+def test_oracle_tree_equals_brute_force_on_random_scenes():
+    # includes quads whose edges do not run along the axes: the reference bounds a quad by two opposite corners
+    # (primitives.h:82-84), which clips such a quad in its own traversal; the canonical semantics are brute force's, and
+    # the oracle's tree must bound all four corners to equal it (it did not until the random scenes of round 3 showed it)
+    from fuzz_scenes import random_scene
+    from computeraytracer_amd import abi
+    for seed in range(8):
+        scene = random_scene(seed, 72, 48)
+        seeds = abi.frame_seeds(0, 2)
+        ps = [scene.params_for(i + 1, seeds[i]) for i in range(2)]
+        a, ia, _ = orc.render(scene, ps, 72, 48, flags=orc.TRAVERSE_BRUTE)
+        b, ib, _ = orc.render(scene, ps, 72, 48, flags=orc.TRAVERSE_FAST)
+        assert np.array_equal(ia, ib) and np.array_equal(a.view(np.uint32), b.view(np.uint32)), seed
