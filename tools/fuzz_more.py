@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""More seeds of tests/test_gpu_fuzz.py than the suite runs: python tools/fuzz_more.py FIRST COUNT (on a GPU box)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from computeraytracer_amd import abi
+import test_gpu_fuzz as t
+
+first, count = int(sys.argv[1]), int(sys.argv[2])
+ctx = abi.Context(0)
+bad = 0
+for seed in range(first, first + count):
+    if (seed - first) % 500 == 0:
+        print("at seed", seed, "failures so far", bad, flush=True)
+    try:
+        t.test_random_scenes_bit_exact_on_every_tree_and_tracer.__wrapped__(ctx, seed) if hasattr(t.test_random_scenes_bit_exact_on_every_tree_and_tracer, "__wrapped__") else t.test_random_scenes_bit_exact_on_every_tree_and_tracer(ctx, seed)
+    except AssertionError as e:
+        bad += 1
+        import traceback
+        print("seed", seed, "FAILED", str(e)[:200], traceback.format_exc().splitlines()[-3].strip(), flush=True)
+print("seeds", first, "..", first + count - 1, "failures", bad, flush=True)
+ctx.close()
+sys.exit(1 if bad else 0)
