@@ -50,3 +50,60 @@ def test_random_scenes_bit_exact_on_every_tree_and_tracer(ctx, seed):
     want = orc.hit_rays(scene, rays)
     hit = want["id"] != abi.ID_MISS                              # crt_ray_hit.t is only meaningful for a hit (crt/types.h)
     assert np.array_equal(got["id"], want["id"]) and np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_configurations_bit_exact(ctx, seed):
+    # the same random scenes under random configurations: ragged frame sizes with and without CRT_FLAG_FULL_IMAGE, both RNG
+    # modes, a band-sharded rank of 1-3, batches of 1-5 iterations continued by single dispatches, animated triangles
+    # followed by a refit or a rebuild
+    rs = np.random.RandomState(77 + seed)
+    w, h = int(rs.randint(9, 90)), int(rs.randint(9, 70))
+    full = bool(rs.randint(0, 2))
+    pcg = bool(rs.randint(0, 2))
+    world = int(rs.randint(1, 4)); rank = int(rs.randint(0, world))
+    n = int(rs.randint(1, 6))
+    scene = random_scene(100 + seed, w, h)
+    seeds = abi.frame_seeds(0, n + 1)
+    ps = [scene.params_for(i + 1, seeds[i]) for i in range(n + 1)]
+    oflags = orc.TRAVERSE_BRUTE | (orc.FULL_IMAGE if full else 0) | (orc.RNG_PCG if pcg else 0) | (orc.BANDS(rank, world) if world > 1 else 0)
+    ref_img, ref_ids, _ = orc.render(scene, ps, w, h, flags=oflags)
+    rows = abi.band_rows(h, rank, world) if world > 1 else np.arange(h)
+    for flags, tracer in [(abi.BVH_SAH_REFINE | abi.BVH_WIDE, abi.TRACER_WAVEFRONT), (abi.BVH_LBVH, abi.TRACER_MEGAKERNEL), (abi.BVH_WIDE_DIRECT, abi.TRACER_WAVEFRONT)]:
+        cfg = dict(tracer=tracer, flags=abi.FLAG_FULL_IMAGE if full else 0, rng_mode=abi.RNG_PCG if pcg else abi.RNG_REF)
+        if world > 1:
+            cfg.update(band_rank=rank, band_world=world)
+        ctx.configure(w, h, **cfg)
+        ctx.upload(scene)
+        ctx.build(flags)
+        ctx.render(ps[0], 1, seeds[:n])              # one batch of n iterations ...
+        ctx.dispatch(ps[n])                          # ... continued by a single dispatch
+        ctx.sync()
+        img, ids = ctx.image(), ctx.hit_ids()
+        assert np.array_equal(ids[rows], ref_ids[rows]), (flags, tracer)
+        assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32)), (flags, tracer, int((img.view(np.uint32) != ref_img.view(np.uint32)).any(axis=2).sum()))
+    if len(scene.tris) == 0:
+        return
+    # move the triangles on the host, hand them over, refit the 8-wide tree (or rebuild): the oracle renders the moved scene
+    moved_tris = scene.tris.copy()
+    shift = rs.uniform(-0.3, 0.3, (len(moved_tris), 3)).astype(np.float32)
+    for k in ("v0", "v1", "v2"):
+        moved_tris[k] = moved_tris[k] + shift
+    moved = abi.HostScene(spheres=scene.spheres, quads=scene.quads, tris=moved_tris, materials=scene.materials, textures=scene.textures, params=scene.params)
+    ref2, ids2, _ = orc.render(moved, ps[:2], w, h, flags=oflags)
+    for how in ("refit", "rebuild"):
+        cfg = dict(tracer=abi.TRACER_WAVEFRONT, flags=abi.FLAG_FULL_IMAGE if full else 0, rng_mode=abi.RNG_PCG if pcg else abi.RNG_REF)
+        if world > 1:
+            cfg.update(band_rank=rank, band_world=world)
+        ctx.configure(w, h, **cfg)
+        ctx.upload(scene)
+        ctx.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE)
+        ctx.tris_update(moved_tris)
+        if how == "refit":
+            ctx.refit()
+        else:
+            ctx.build(abi.BVH_WIDE_DIRECT)
+        ctx.render(ps[0], 1, seeds[:2]); ctx.sync()
+        img, ids = ctx.image(), ctx.hit_ids()
+        assert np.array_equal(ids[rows], ids2[rows]), how
+        assert np.array_equal(img.view(np.uint32), ref2.view(np.uint32)), how
