@@ -172,6 +172,15 @@ if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and requested_gpus(
     # `python bench.py --gpus N` on its own: become the launcher before anything GPU-related is imported
     sys.exit(launch_ranks(sys.argv[1:], requested_gpus(sys.argv[1:])))
 
+if __name__ == "__main__" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # A rank of a multi-GPU run.  The contract is ONE JSON line on stdout, and native libraries write to file descriptor 1
+    # on their own (Gloo's "[Gloo] Rank 3 is connected to ..." lines, RCCL's NCCL_DEBUG output): descriptor 1 goes to stderr
+    # for them, and Python's sys.stdout (the JSON line, nothing else) keeps the original.
+    sys.stdout.flush()
+    _json_out = os.fdopen(os.dup(1), "w", buffering=1)
+    os.dup2(2, 1)
+    sys.stdout = _json_out
+
 if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("CRT_BENCH_FORCE_DIST", "") == "1":
     # PyTorch-ROCm bundles its own HIP runtime (same soname as /opt/rocm's).  Loaded first, libcrt.so binds to that one
     # copy; loaded second, the process ends up with two runtimes and the second cannot open the GPU.
