@@ -829,6 +829,7 @@ int crt_image_export_fd(crt_context *ctx, int *fd, size_t *image_bytes, size_t *
     int rc = bind(ctx); if (rc) return rc;
     if (!ctx->configured) return fail(ctx, CRT_ERR_INVALID, "crt_image_export_fd: not configured");
     const size_t need = (size_t)ctx->local_rows * ctx->cfg.width * 16;
+    if (need == 0) return fail(ctx, CRT_ERR_INVALID, "crt_image_export_fd: this rank owns no rows of the frame");
     crt_context::ExportImage &x = ctx->exported;
     if (x.live && x.image_bytes != need) {      // a different frame size: importers hold their own reference to the old memory
         CTX_HIP(hipStreamSynchronize(ctx->stream));
