@@ -322,8 +322,8 @@ def cpu_baseline(scene, target_s=12.0):
     seeds = abi.frame_seeds(0, 2049)
     orc.render(small, [small.params_for(1, seeds[0])], w, h, flags=orc.TRAVERSE_FAST, threads=threads, want_ids=False)   # warm: BVH, threads
     t0 = time.perf_counter()
-    _, _, c = orc.render(small, [small.params_for(i + 1, seeds[i]) for i in range(4)], w, h, flags=orc.TRAVERSE_FAST, threads=threads, want_ids=False)
-    one = (time.perf_counter() - t0) / 4
+    _, _, c = orc.render(small, [small.params_for(i + 1, seeds[i]) for i in range(16)], w, h, flags=orc.TRAVERSE_FAST, threads=threads, want_ids=False)
+    one = (time.perf_counter() - t0) / 16     # (a four-iteration probe read 1.8x high and the sample came out at 6.8 s instead of ~12)
     n = int(max(1, min(2048, target_s / max(one, 1e-4))))
     t0 = time.perf_counter()
     _, _, c = orc.render(small, [small.params_for(i + 2, seeds[i + 1]) for i in range(n)], w, h, flags=orc.TRAVERSE_FAST,
