@@ -76,10 +76,11 @@ __global__ __launch_bounds__(256) void k_valu(int trips, float seed, float *out)
         float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f; \
         float m = 0.999f + seed * 1e-9f, c = 0.001f + seed * 1e-9f;                                                      \
         uint32_t w = __float_as_uint(seed) + threadIdx.x;                                                                \
+        float den = __uint_as_float(threadIdx.x & 255u);      /* a denormal operand */                                      \
         for (int t = 0; t < trips; t++) {                                                                                \
             _Pragma("unroll") for (int u = 0; u < kUnroll; u++) {                                                        \
                 asm volatile(ASM8 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)      \
-                             : [m] "v"(m), [c] "v"(c), [w] "v"(w) : "vcc", "s10", "s11");                                              \
+                             : [m] "v"(m), [c] "v"(c), [w] "v"(w), [d] "v"(den) : "vcc", "s10", "s11");                                              \
             }                                                                                                            \
         }                                                                                                                \
         out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                     \
@@ -136,6 +137,11 @@ __global__ __launch_bounds__(256) void k_valu(int trips, float seed, float *out)
 #define I_FMAABS(k) "v_fma_f32 %" #k ", |%" #k "|, %[m], -%[c]\n"
 #define I_ADDE64(k) "v_add_f32_e64 %" #k ", %" #k ", %[m]\n"
 #define I_MOVS(k) "v_mov_b32 %" #k ", s10\n"
+#define I_MULSDWA(k) "v_mul_f32_sdwa %" #k ", %[m], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
+#define I_ADDSDWA(k) "v_add_f32_sdwa %" #k ", %" #k ", %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n"
+#define I_ORSDWA(k) "v_or_b32_sdwa %" #k ", %[c], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
+#define I_FMAMIX(k) "v_fma_mix_f32 %" #k ", %[w], %[m], %" #k " op_sel_hi:[1,0,0]\n"
+#define I_MULDEN(k) "v_mul_f32 %" #k ", %[m], %[d]\n"
 #define I_MOVLIT(k) "v_mov_b32 %" #k ", 0x3f7fbe77\n"
 SURVEY_KERNEL(add, R8(I_ADD)) SURVEY_KERNEL(mul, R8(I_MUL)) SURVEY_KERNEL(sub, R8(I_SUB)) SURVEY_KERNEL(max, R8(I_MAX)) SURVEY_KERNEL(min, R8(I_MIN))
 SURVEY_KERNEL(max3, R8(I_MAX3)) SURVEY_KERNEL(med3, R8(I_MED3)) SURVEY_KERNEL(mov, R8(I_MOV)) SURVEY_KERNEL(and_, R8(I_AND)) SURVEY_KERNEL(or_, R8(I_OR))
@@ -150,6 +156,7 @@ SURVEY_KERNEL(xor_, R8(I_XOR)) SURVEY_KERNEL(subrev, R8(I_SUBREV)) SURVEY_KERNEL
 SURVEY_KERNEL(mullit, R8(I_MULLIT)) SURVEY_KERNEL(mulinl, R8(I_MULINL)) SURVEY_KERNEL(andlit, R8(I_ANDLIT)) SURVEY_KERNEL(andinl, R8(I_ANDINL))
 SURVEY_KERNEL(ands, "s_mov_b32 s10, 0x3f7fbe77\n" R8(I_ANDS)) SURVEY_KERNEL(fmainl, R8(I_FMAINL)) SURVEY_KERNEL(fmaabs, R8(I_FMAABS))
 SURVEY_KERNEL(adde64, R8(I_ADDE64)) SURVEY_KERNEL(movs, "s_mov_b32 s10, 0x3f7fbe77\n" R8(I_MOVS)) SURVEY_KERNEL(movlit, R8(I_MOVLIT))
+SURVEY_KERNEL(mulsdwa, R8(I_MULSDWA)) SURVEY_KERNEL(addsdwa, R8(I_ADDSDWA)) SURVEY_KERNEL(orsdwa, R8(I_ORSDWA)) SURVEY_KERNEL(fmamix, R8(I_FMAMIX)) SURVEY_KERNEL(mulden, R8(I_MULDEN))
 SURVEY_KERNEL(fmas, "s_mov_b32 s10, 0x3f7fbe77\n" R8(I_FMAS)) SURVEY_KERNEL(fmas2, "s_mov_b32 s10, 0x3f7fbe77\n" R8(I_FMAS2)) SURVEY_KERNEL(muls, "s_mov_b32 s10, 0x3f7fbe77\n" R8(I_MULS))
 
 typedef void (*survey_fn)(int, float, float *);
@@ -219,6 +226,7 @@ int main() {
             printf("%-18s %6d %14.4f %14.2f\n", names[kind], w, r, r * 64.0);
         }
     struct { const char *name; survey_fn fn; } sv[] = {
+        {"v_mul_f32_sdwa byte (denormal src)", k_sv_mulsdwa}, {"v_add_f32_sdwa byte", k_sv_addsdwa}, {"v_or_b32_sdwa byte", k_sv_orsdwa}, {"v_fma_mix_f32 f16 src0", k_sv_fmamix}, {"v_mul_f32 denormal src", k_sv_mulden},
         {"v_mul_f32 literal", k_sv_mullit}, {"v_mul_f32 inline 1.0", k_sv_mulinl}, {"v_and_b32 literal", k_sv_andlit}, {"v_and_b32 inline 63", k_sv_andinl}, {"v_and_b32 sgpr (x8/9)", k_sv_ands},
         {"v_fma_f32 inline 1.0 src2", k_sv_fmainl}, {"v_fma_f32 abs/neg modifiers", k_sv_fmaabs}, {"v_add_f32_e64 (VOP3 encoding)", k_sv_adde64},
         {"v_mov_b32 sgpr (x8/9)", k_sv_movs}, {"v_mov_b32 literal", k_sv_movlit},
