@@ -64,6 +64,7 @@ class Phase:
     def __init__(self, rank):
         self.rank, self.name, self.t0 = rank, "start", time.time()
         self.pending = None      # rank 0: the finished result line while the (untimed) image gather is still running
+        self.measured_t = None   # every rank: when the timed measurement (and its reduction over ranks) was complete
         d = os.environ.get("CRT_BENCH_PHASE_DIR", "")
         self.path = os.path.join(d, f"rank_{rank}") if d else None
         self.set("start")
@@ -87,17 +88,25 @@ def start_watchdog(phase, world, seconds):
     import threading
 
     def watch():
-        while time.time() - phase.t0 < seconds:
+        # two limits: `seconds` for the whole run, and CRT_BENCH_GATHER_TIMEOUT (120 s) for what follows the measurement
+        # (communicator set-up, the image gather, the final barrier): a hang there must not cost the result, nor minutes
+        gather_limit = float(os.environ.get("CRT_BENCH_GATHER_TIMEOUT", "120"))
+        while time.time() - phase.t0 < seconds and not (phase.measured_t is not None and time.time() - phase.measured_t > gather_limit):
             if phase.name == "done":
                 return
             time.sleep(0.25)
         if phase.name == "done":
             return
-        pending = phase.pending
-        if pending is not None:      # the measurement is complete, only the gather of the image is stuck: report it as what it is
-            pending["config"]["gather"] = f"failed: timeout in phase {phase.name} after {round(time.time() - phase.t0, 1)} s"
-            pending["config"]["gather_ms"], pending["config"]["gather_check"] = None, None
-            print(json.dumps(pending), flush=True)
+        if phase.measured_t is not None:
+            # The measurement is complete and rank 0 has (or had) the whole line; only the gather of the image or the
+            # shutdown is stuck.  Rank 0 reports the line with the gather marked as failed; every rank ends with exit code 0,
+            # so that a launcher (torch.distributed.run) does not turn a finished measurement into a failed run.
+            pending = phase.pending
+            if pending is not None:
+                pending["config"]["gather"] = f"failed: timeout in phase {phase.name} after {round(time.time() - phase.measured_t, 1)} s"
+                pending["config"]["gather_ms"], pending["config"]["gather_check"] = None, None
+                print(json.dumps(pending), flush=True)
+            print(f"bench.py: rank {phase.rank} stuck in phase {phase.name} after the measurement; ending", file=sys.stderr, flush=True)
             os._exit(0)
         print(json.dumps({"error": "timeout", "rank": phase.rank, "n_gpus": world, "phase": phase.name,
                           "after_s": round(time.time() - phase.t0, 1)}), flush=True)
@@ -668,6 +677,7 @@ def main():
         # the gather marked as failed) if a rank gets stuck in the communicator set-up or in the collective.
         if rank == 0:
             phase.pending = line
+        phase.measured_t = time.time()
         try:
             gather_ms, gather_path, gather_check = gather_phase()
         except Exception as e:      # noqa: BLE001 -- the result must not be lost to the untimed gather
@@ -675,8 +685,8 @@ def main():
                 line["config"]["gather"] = f"failed in phase {phase.name}: {e}"
                 line["config"]["gather_ms"], line["config"]["gather_check"] = None, None
                 print(json.dumps(line), flush=True)
-                os._exit(0)         # the other ranks may be inside a collective that will never complete
-            raise
+            print(f"bench.py: rank {rank}: image gather failed in phase {phase.name}: {e}", file=sys.stderr, flush=True)
+            os._exit(0)             # other ranks may be inside a collective that will never complete; the measurement stands
         if rank == 0:
             phase.pending = None
             line["config"]["gather_ms"] = None if gather_ms is None else round(gather_ms, 3)

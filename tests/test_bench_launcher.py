@@ -127,13 +127,35 @@ def test_rank_watchdog_prints_the_finished_line_when_only_the_gather_hangs(tmp_p
         "import importlib.util\n"
         "spec = importlib.util.spec_from_file_location('crt_bench', %r)\n"
         "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
-        "ph = m.Phase(0); m.start_watchdog(ph, 8, 1.0)\n"
+        "ph = m.Phase(0); m.start_watchdog(ph, 8, 300.0)\n"      # the whole-run limit is far away: the gather limit fires
         "ph.pending = {'metric': 'x', 'value': 123.0, 'n_gpus': 8, 'config': {'gather': None, 'gather_ms': 1.0, 'gather_check': 'ok'}}\n"
+        "ph.measured_t = time.time()\n"
         "ph.set('comm_init')\n"
         "time.sleep(30)\n" % os.path.join(ROOT, "bench.py"))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")}
+    env["CRT_BENCH_GATHER_TIMEOUT"] = "1"
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=env)
     assert r.returncode == 0
     lines = _json_lines(r.stdout)
     assert len(lines) == 1 and lines[0]["value"] == 123.0 and "error" not in lines[0]
     assert lines[0]["config"]["gather"].startswith("failed: timeout in phase comm_init") and lines[0]["config"]["gather_check"] is None
+
+
+def test_other_ranks_end_quietly_with_exit_code_0_when_the_gather_hangs_after_the_measurement(tmp_path):
+    # under torch.distributed.run every rank's stdout is the job's stdout and a non-zero exit fails the job: a rank that is
+    # stuck in the gather AFTER the measurement prints no JSON of its own and does not fail the run
+    import subprocess
+    code = (
+        "import os, sys, time\n"
+        "sys.argv = ['bench.py']\n"
+        "import importlib.util\n"
+        "spec = importlib.util.spec_from_file_location('crt_bench', %r)\n"
+        "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+        "ph = m.Phase(3); m.start_watchdog(ph, 8, 300.0)\n"
+        "ph.measured_t = time.time()\n"
+        "ph.set('first_gather')\n"
+        "time.sleep(30)\n" % os.path.join(ROOT, "bench.py"))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")}
+    env["CRT_BENCH_GATHER_TIMEOUT"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 0 and _json_lines(r.stdout) == [] and "rank 3 stuck in phase first_gather" in r.stderr
