@@ -385,10 +385,11 @@ def main():
         import torch.distributed as dist
         phase.set("dist_init")
         torch.cuda.set_device(local_rank)
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # Two backends in one group: gloo carries the control plane (barriers, the reductions of a few scalars, the 128-byte
+        # communicator id: CPU tensors), RCCL carries the image (libcrt.so's own communicator, or torch's for CUDA tensors in
+        # the fallback gather; torch makes its communicator at the first CUDA collective, not here).  The measurement then
+        # does not depend on a communicator that the (untimed) gather may fail to make.
+        dist.init_process_group("gloo" if rehearse else "cpu:gloo,cuda:nccl")
 
     scene_name, W, H, label = WORKLOADS[args.workload]
     asset_dir = os.path.join(ROOT, "tests", "golden")
@@ -458,9 +459,13 @@ def main():
     kernel_timing = not rebuild and os.environ.get("CRT_BENCH_NO_KERNEL_TIMING", "") != "1"
     ctx.set_kernel_timing(kernel_timing)
 
+    def host_barrier():
+        import torch
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64))      # a CPU tensor: gloo (dist.barrier() may pick the CUDA backend)
+
     def barrier():
         if dist is not None:
-            dist.barrier()
+            host_barrier()
             import torch
             torch.cuda.synchronize()
         ctx.sync()
@@ -483,7 +488,7 @@ def main():
     if dist is not None:
         import torch
         phase.set("reduce")
-        tdev = torch.device("cpu") if rehearse else torch.device("cuda", local_rank)
+        tdev = torch.device("cpu")      # control plane: gloo
         t = torch.tensor([elapsed, rays], dtype=torch.float64, device=tdev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -499,7 +504,7 @@ def main():
         per_rank_rays = [float(x) for x in per[:, 1]]
     def gather_phase():
         import torch
-        tdev = torch.device("cpu") if rehearse else torch.device("cuda", local_rank)
+        tdev = torch.device("cpu")      # control plane: gloo
         gather_ms, gather_check = None, None
         # gather the finished image: ONE all-gather of the packed band buffers + un-interleave, outside `value`
         gather_path = "rccl-native"
@@ -508,7 +513,7 @@ def main():
             gather_path = "torch-gloo-rehearsal"
             from computeraytracer_amd import dist as cdist
             band = cdist.context_band_tensor(ctx, W, torch.device("cuda", local_rank)).to(tdev)
-            torch.cuda.synchronize(); dist.barrier()
+            torch.cuda.synchronize(); host_barrier()
             g0 = time.perf_counter()
             image = cdist.gather_image(band, H, world)
             torch.cuda.synchronize()
@@ -545,7 +550,7 @@ def main():
             if ok:
                 phase.set("first_gather")
                 ctx.image_gather(); ctx.sync()            # the first collective on a communicator sets its channels up: untimed
-                torch.cuda.synchronize(); dist.barrier()
+                torch.cuda.synchronize(); host_barrier()
                 phase.set("timed_gather")
                 g0 = time.perf_counter()
                 ctx.image_gather(); ctx.sync()
@@ -557,7 +562,7 @@ def main():
                 gather_path = "torch-nccl-fallback (native communicator unavailable" + (": " + native_error if native_error else " on another rank") + ")"
                 from computeraytracer_amd import dist as cdist
                 band = cdist.context_band_tensor(ctx, W, torch.device("cuda", local_rank))
-                torch.cuda.synchronize(); dist.barrier()
+                torch.cuda.synchronize(); host_barrier()
                 g0 = time.perf_counter()
                 image = cdist.gather_image(band, H, world)
                 torch.cuda.synchronize()
@@ -696,7 +701,7 @@ def main():
         print(json.dumps(line), flush=True)
     ctx.close()
     if dist is not None:
-        dist.barrier()
+        host_barrier()
         dist.destroy_process_group()
     phase.set("done")
 

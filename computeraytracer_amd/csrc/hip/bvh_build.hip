@@ -126,9 +126,9 @@ __global__ __launch_bounds__(256) void k_tri_bounds(const crt_tri *tris, uint32_
                 phi[g] = make_float4(hi[0], hi[1], hi[2], 0.0f);
             } else plo[g] = make_float4(0.5f * lo[0] + 0.5f * hi[0], 0.5f * lo[1] + 0.5f * hi[1], 0.5f * lo[2] + 0.5f * hi[2], 0.0f);
             for (int a = 0; a < 3; a++) { const uint32_t e = enc_f(0.5f * lo[a] + 0.5f * hi[a]); cmn[a] = min(cmn[a], e); cmx[a] = max(cmx[a], e); }
-            o0 = make_float4(v0.x, v0.y, v0.z, v1.x - v0.x);
-            o1 = make_float4(v1.y - v0.y, v1.z - v0.z, v2.x - v0.x, v2.y - v0.y);
-            o2 = make_float4(v2.z - v0.z, last.w, tu.x, tu.y);
+            float e20z;
+            tri_record_head(v0, v1, v2, o0, o1, e20z);
+            o2 = make_float4(e20z, last.w, tu.x, tu.y);
             o3 = make_float4(tu.z, tv.x, tv.y, tv.z);
         }
         __syncthreads();
@@ -529,9 +529,9 @@ __global__ __launch_bounds__(256) void k_animate_tris(uint32_t n, const crt_tri 
                 pad_box(lo, hi);
                 plo[base + lane] = make_float4(0.5f * lo[0] + 0.5f * hi[0], 0.5f * lo[1] + 0.5f * hi[1], 0.5f * lo[2] + 0.5f * hi[2], 0.0f);
                 for (int a = 0; a < 3; a++) { const uint32_t e = enc_f(0.5f * lo[a] + 0.5f * hi[a]); cmn[a] = min(cmn[a], e); cmx[a] = max(cmx[a], e); }
-                o0 = make_float4(v0.x, v0.y, v0.z, v1.x - v0.x);
-                o1 = make_float4(v1.y - v0.y, v1.z - v0.z, v2.x - v0.x, v2.y - v0.y);
-                o2 = make_float4(v2.z - v0.z, last.w, tu.x, tu.y);
+                float e20z;
+                tri_record_head(v0, v1, v2, o0, o1, e20z);
+                o2 = make_float4(e20z, last.w, tu.x, tu.y);
                 o3 = make_float4(tu.z, tv.x, tv.y, tv.z);
             }
         }

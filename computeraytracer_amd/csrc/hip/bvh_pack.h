@@ -41,6 +41,23 @@ __device__ __forceinline__ void prim_box(const BuildInput &in, uint32_t g, float
     pad_box(lo, hi);
 }
 
+// Head of a triangle's 64-byte shading record (and, copied from there, of its traversal record): v0, e10 = v1 - v0,
+// e20 = v2 - v0, the two IEEE subtractions of hit_tri (compute.comp:281-282).  A triangle of ZERO AREA (cross(e10, e20)
+// == 0 exactly: a repeated vertex, as real meshes have them) gets e10 = e20 = 0 and is then never hit (hit_tri's
+// determinant is 0).  With the uploaded edges its determinant e10 . (d x e20) is rounding noise of either sign, often above
+// the shader's 1e-8 threshold, and the beta / gamma tests then pass for rays that run close to the triangle's LINE, at
+// distances that need not lie inside the triangle's box: whether such a ray "hits" depends on whether the traversal
+// happens to reach the leaf, i.e. on the tree (found by the random-scene tests: one ray in 4 x 10^8).  The oracle's
+// canonical modes apply the same rule (oracle.cpp: hit_tri); its reference mode keeps the shader's behaviour.
+__device__ __forceinline__ void tri_record_head(const float4 &v0, const float4 &v1, const float4 &v2, float4 &o0, float4 &o1, float &e20z) {
+    float e1[3] = {v1.x - v0.x, v1.y - v0.y, v1.z - v0.z}, e2[3] = {v2.x - v0.x, v2.y - v0.y, v2.z - v0.z};
+    const float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+    if (cx == 0.0f && cy == 0.0f && cz == 0.0f) { e1[0] = e1[1] = e1[2] = 0.0f; e2[0] = e2[1] = e2[2] = 0.0f; }
+    o0 = make_float4(v0.x, v0.y, v0.z, e1[0]);
+    o1 = make_float4(e1[1], e1[2], e2[0], e2[1]);
+    e20z = e2[2];
+}
+
 // Traversal record of sorted position s (primitive g) into its kind's array; returns the kind and the slot there.
 // WANT_BOX: also the primitive's padded box.  Spheres and quads: prim_box's own arithmetic on the record read here anyway.
 // Triangles: from the record's v0, v0 + e10, v0 + e20, i.e. corners at most an ulp from the uploaded ones, which is far

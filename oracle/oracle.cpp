@@ -379,6 +379,13 @@ inline void hit_tri(const Ray &ray, const Tri &tr, uint32_t id, bool canonical, 
     V3 v0 = v3(tr.v0);
     V3 e10 = v3(tr.v1) - v0;
     V3 e20 = v3(tr.v2) - v0;
+    if (canonical) {
+        // Zero-area triangles (a repeated vertex) are never hit: their determinant is rounding noise, and which rays "hit"
+        // them then depends on the tree (a hit can lie outside the triangle's box), so no order-independent answer exists.
+        // The device zeroes their edges at build time (bvh_pack.h: tri_record_head); ORC_TRAVERSE_REF keeps the shader's way.
+        const V3 n0 = cross(e10, e20);
+        if (n0.x == 0.0f && n0.y == 0.0f && n0.z == 0.0f) return;
+    }
     V3 p = cross(ray.d, e20);
     float det = dot(e10, p);
     if (fabsf(det) < 1e-8f) return;

@@ -23,7 +23,7 @@ TREES = [("lbvh", abi.BVH_LBVH, True), ("sah", abi.BVH_SAH_REFINE, True), ("coll
          ("sah-wide", abi.BVH_SAH_REFINE | abi.BVH_WIDE, True), ("direct", abi.BVH_WIDE_DIRECT, False)]
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", list(range(8)) + [82206])      # 82206: a ray that "hit" a zero-area triangle by rounding noise
 def test_random_scenes_bit_exact_on_every_tree_and_tracer(ctx, seed):
     w, h, n = 72, 48, 3
     scene = random_scene(seed, w, h)
@@ -107,3 +107,49 @@ def test_random_configurations_bit_exact(ctx, seed):
         img, ids = ctx.image(), ctx.hit_ids()
         assert np.array_equal(ids[rows], ids2[rows]), how
         assert np.array_equal(img.view(np.uint32), ref2.view(np.uint32)), how
+
+
+def test_zero_area_triangles_are_never_hit(ctx):
+    # A triangle with a repeated vertex has determinant e10 . (d x e20) = rounding noise; the shader's test then accepts
+    # rays that run close to the triangle's line, at distances outside the triangle's box, so whether such a ray hits
+    # depends on the tree.  The build zeroes the edges of zero-area triangles (bvh_pack.h: tri_record_head) and the
+    # oracle's canonical modes skip them: every tree answers like the exhaustive test.  Rays here are aimed along and
+    # across those lines from many origins, which is where the noise hits live.
+    rs = np.random.RandomState(5)
+    n_deg, n_real = 64, 64
+    tris = np.zeros(n_deg + n_real, abi.tri_dtype)
+    a = rs.uniform(-2, 2, (n_deg + n_real, 3)).astype(np.float32)
+    b = (a + rs.uniform(-1.5, 1.5, a.shape)).astype(np.float32)
+    c = (a + rs.uniform(-1.5, 1.5, a.shape)).astype(np.float32)
+    kind = rs.randint(0, 3, n_deg)
+    c[:n_deg] = b[:n_deg]                                    # v1 == v2
+    b[:n_deg][kind == 1] = a[:n_deg][kind == 1]              # v0 == v1
+    sel = kind == 2
+    c[:n_deg][sel] = a[:n_deg][sel]; b[:n_deg][sel] = (a[:n_deg][sel] + np.float32(0.75))      # v0 == v2
+    tris["v0"], tris["v1"], tris["v2"] = a, b, c
+    tris["materialIndex"] = 0
+    base = random_scene(3, 64, 64)
+    scene = abi.HostScene(spheres=base.spheres[:0], quads=base.quads[:0], tris=tris, materials=base.materials, textures=base.textures, params=base.params)
+    rays = np.zeros(n_deg * 512, abi.ray_dtype)
+    k = np.repeat(np.arange(n_deg), 512)
+    p0, p1 = a[k], np.where((kind == 1)[k, None], c[k], b[k])
+    s = rs.uniform(-1.5, 2.5, (len(k), 1)).astype(np.float32)
+    target = (p0 + (p1 - p0) * s + rs.standard_normal((len(k), 3)).astype(np.float32) * np.float32(1e-6)).astype(np.float32)
+    origin = (target + rs.standard_normal((len(k), 3)).astype(np.float32) * np.float32(3.0)).astype(np.float32)
+    along = rs.randint(0, 2, len(k)).astype(bool)            # half of the rays run ALONG the line instead of across it
+    origin[along] = (p0[along] - (p1[along] - p0[along]) * np.float32(2.0) + rs.standard_normal((int(along.sum()), 3)).astype(np.float32) * np.float32(1e-5)).astype(np.float32)
+    d = target - origin
+    rays["origin"] = origin
+    rays["direction"] = d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-20).astype(np.float32)
+    rays["t_max"] = np.inf
+    want = orc.hit_rays(scene, rays)
+    assert not np.isin(want["id"][want["id"] != abi.ID_MISS] & 0x3FFFFFFF, np.arange(n_deg)).any()
+    assert (want["id"] != abi.ID_MISS).sum() > 100           # the real triangles are still hit
+    for name, flags, _ in TREES:
+        ctx.configure(64, 64, tracer=abi.TRACER_WAVEFRONT)
+        ctx.upload(scene)
+        ctx.build(flags)
+        got = ctx.rays_query(rays, abi.QUERY_CLOSEST)
+        hit = want["id"] != abi.ID_MISS
+        assert np.array_equal(got["id"], want["id"]), (name, int((got["id"] != want["id"]).sum()))
+        assert np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32)), name
