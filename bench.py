@@ -181,9 +181,9 @@ if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and requested_gpus(
     # `python bench.py --gpus N` on its own: become the launcher before anything GPU-related is imported
     sys.exit(launch_ranks(sys.argv[1:], requested_gpus(sys.argv[1:])))
 
-if __name__ == "__main__" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+if __name__ == "__main__" and (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("CRT_BENCH_FORCE_DIST", "") == "1"):
     # A rank of a multi-GPU run.  The contract is ONE JSON line on stdout, and native libraries write to file descriptor 1
-    # on their own (Gloo's "[Gloo] Rank 3 is connected to ..." lines, RCCL's NCCL_DEBUG output): descriptor 1 goes to stderr
+    # on their own (Gloo's "[Gloo] Rank 3 is connected to ..." lines, RCCL's version banner and NCCL_DEBUG output): descriptor 1 goes to stderr
     # for them, and Python's sys.stdout (the JSON line, nothing else) keeps the original.
     sys.stdout.flush()
     _json_out = os.fdopen(os.dup(1), "w", buffering=1)
