@@ -153,3 +153,27 @@ def test_zero_area_triangles_are_never_hit(ctx):
         hit = want["id"] != abi.ID_MISS
         assert np.array_equal(got["id"], want["id"]), (name, int((got["id"] != want["id"]).sum()))
         assert np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32)), name
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_ray_queries_from_random_origins(ctx, seed):
+    # closest-hit and any-hit queries whose origins lie anywhere in the scene (inside spheres, behind quads, between the
+    # triangles), with finite and infinite t_max, on two trees; the any-hit answer is "some primitive in the interval"
+    scene = random_scene(500 + seed, 72, 48)
+    rs = np.random.RandomState(900 + seed)
+    n = 8192
+    rays = np.zeros(n, abi.ray_dtype)
+    rays["origin"] = (rs.uniform(-8, 8, (n, 3)) * np.float32([1, 0.4, 1])).astype(np.float32)
+    d = rs.standard_normal((n, 3)).astype(np.float32)
+    rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    rays["t_max"] = np.where(rs.randint(0, 2, n) == 0, np.float32(np.inf), rs.uniform(0.5, 12.0, n).astype(np.float32))
+    want = orc.hit_rays(scene, rays)
+    hit = want["id"] != abi.ID_MISS
+    ctx.configure(72, 48, tracer=abi.TRACER_WAVEFRONT)
+    ctx.upload(scene)
+    for flags in (abi.BVH_SAH_REFINE | abi.BVH_WIDE, abi.BVH_LBVH):
+        ctx.build(flags)
+        got = ctx.rays_query(rays, abi.QUERY_CLOSEST)
+        assert np.array_equal(got["id"], want["id"]) and np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32)), flags
+        anyhit = ctx.rays_query(rays, abi.QUERY_ANY)
+        assert np.array_equal(anyhit["id"] != abi.ID_MISS, hit), flags
