@@ -43,7 +43,9 @@ typedef struct crt_quad {
     uint32_t materialIndex;
 } crt_quad;
 
-/* Tri::GPU_t, primitives.h:123-131; compute.comp:51-59 (96 B) */
+/* Tri::GPU_t, primitives.h:123-131; compute.comp:51-59 (96 B).  A triangle of zero area (cross(v1 - v0, v2 - v0) == 0
+ * exactly: a repeated vertex) is never hit: the shader's determinant is rounding noise for it and which rays it "hits" would
+ * depend on the tree. */
 typedef struct crt_tri {
     float v0[3]; float pad0;
     float v1[3]; float pad1;
