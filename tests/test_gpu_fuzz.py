@@ -177,3 +177,43 @@ def test_random_ray_queries_from_random_origins(ctx, seed):
         assert np.array_equal(got["id"], want["id"]) and np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32)), flags
         anyhit = ctx.rays_query(rays, abi.QUERY_ANY)
         assert np.array_equal(anyhit["id"] != abi.ID_MISS, hit), flags
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scenes_with_build_extensions(ctx, seed):
+    # the two build extensions (per-material texture index, alpha-tested textured triangles), alone and together, on
+    # random scenes whose texture has random alpha: paths and ray queries (closest and any hit) against the oracle
+    rs = np.random.RandomState(300 + seed)
+    w, h = 56, 40
+    scene = random_scene(700 + seed, w, h)
+    ext = [abi.EXT_TEXTURE_INDEX, abi.EXT_ALPHA_TEST, abi.EXT_TEXTURE_INDEX | abi.EXT_ALPHA_TEST][seed % 3]
+    oext = (orc.EXT_TEXTURE_INDEX if ext & abi.EXT_TEXTURE_INDEX else 0) | (orc.EXT_ALPHA_TEST if ext & abi.EXT_ALPHA_TEST else 0)
+    mats = scene.materials.copy()
+    mats["textureIndex"][: 1 + seed % 3] = 0                  # a few more textured materials (of whatever type)
+    scene = abi.HostScene(spheres=scene.spheres, quads=scene.quads, tris=scene.tris, materials=mats, textures=scene.textures, params=scene.params)
+    seeds = abi.frame_seeds(0, 3)
+    ps = [scene.params_for(i + 1, seeds[i]) for i in range(3)]
+    ref_img, ref_ids, _ = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_BRUTE | oext)
+    n = 4096
+    rays = np.zeros(n, abi.ray_dtype)
+    rays["origin"] = (rs.uniform(-8, 8, (n, 3)) * np.float32([1, 0.4, 1])).astype(np.float32)
+    d = rs.standard_normal((n, 3)).astype(np.float32)
+    rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    rays["t_max"] = np.inf
+    want = orc.hit_rays(scene, rays, flags=orc.TRAVERSE_BRUTE | oext)
+    hit = want["id"] != abi.ID_MISS
+    try:
+        for flags, tracer in [(abi.BVH_SAH_REFINE | abi.BVH_WIDE, abi.TRACER_WAVEFRONT), (abi.BVH_LBVH, abi.TRACER_MEGAKERNEL), (abi.BVH_WIDE_DIRECT, abi.TRACER_WAVEFRONT)]:
+            ctx.configure(w, h, tracer=tracer)
+            ctx.extensions_set(ext)
+            ctx.upload(scene)
+            ctx.build(flags)
+            ctx.render(ps[0], 1, seeds); ctx.sync()
+            img, ids = ctx.image(), ctx.hit_ids()
+            assert np.array_equal(ids, ref_ids), (flags, tracer, ext)
+            assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32)), (flags, tracer, ext)
+            got = ctx.rays_query(rays, abi.QUERY_CLOSEST)
+            assert np.array_equal(got["id"], want["id"]) and np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32)), (flags, ext)
+            assert np.array_equal(ctx.rays_query(rays, abi.QUERY_ANY)["id"] != abi.ID_MISS, hit), (flags, ext)
+    finally:
+        ctx.extensions_set(0)
