@@ -641,10 +641,18 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
         if (direct || fit >= half_log) { idx_bits = ib; bits = std::min(bits, fit); }      // direct: n < 2^24 leaves 13 bits per axis at least
     }
     const unsigned key_bits = 3 * bits;
+    // rocPRIM 4.2's radix_sort_keys(double_buffer) with begin_bit > 0 leaves 64-bit keys sorted inside 1024-key blocks only
+    // wherever it merge-sorts (1025 .. 2^20 keys; tools/src/rocprim_sort_check.hip, profiles/r03_rocprim_sort_check.txt): up
+    // to there the packed keys are sorted over ALL their bits, which gives the same order (the index in the low bits is what a
+    // stable sort by code would have kept) at the same cost (a merge sort does not care about the key width).  Found by the
+    // random soups of tests/test_gpu_fuzz.py: a direct build of a few thousand primitives got a valid but badly cut tree
+    // (any partition of the primitives makes a correct BVH, which is why no parity test noticed), and now and then a cut
+    // search that never ended.
+    const unsigned sort_lo = (idx_bits && n <= (1u << 20)) ? 0u : idx_bits;
     rocprim::double_buffer<uint64_t> dkeys((uint64_t *)st.keys.ptr, (uint64_t *)st.keys_alt.ptr);
     rocprim::double_buffer<uint32_t> dvals((uint32_t *)st.vals.ptr, (uint32_t *)st.vals_alt.ptr);
     if (direct && n >= (1u << 24)) { err = "wide BVH supports fewer than 2^24 primitives"; return false; }
-    if (idx_bits) HIP_TRY(rocprim::radix_sort_keys(nullptr, sort_bytes, dkeys, n, idx_bits, idx_bits + key_bits, stream));
+    if (idx_bits) HIP_TRY(rocprim::radix_sort_keys(nullptr, sort_bytes, dkeys, n, sort_lo, idx_bits + key_bits, stream));
     else HIP_TRY(rocprim::radix_sort_pairs<PairSortConfig>(nullptr, sort_bytes, dkeys, dvals, n, 0, key_bits, stream));
     HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t *)st.flag_a.ptr, (uint32_t *)st.rank_a.ptr, 0u, n,
                                     rocprim::plus<uint32_t>(), stream));
@@ -687,6 +695,7 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, bits, idx_bits, (const float4 *)st.plo.ptr,
                        direct ? (const float4 *)nullptr : (const float4 *)st.phi.ptr, (const uint32_t *)st.scene_bounds.ptr, (uint64_t *)st.keys.ptr, (uint32_t *)st.vals.ptr);
     HIP_TRY(hipGetLastError());
+    build_trace(stream, "bounds + morton", n);
     size_t tb = st.temp.bytes;
     const uint64_t *keys = nullptr; const uint32_t *sort_error = nullptr;
     const uint32_t *own_vals = nullptr;
@@ -695,11 +704,12 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
                             n, idx_bits, idx_bits + key_bits, st.temp.ptr, &keys, &own_vals, &sort_error, err)) return false;
         if (!direct) st.sort_error_dev = sort_error;
     } else {
-        if (idx_bits) HIP_TRY(rocprim::radix_sort_keys(st.temp.ptr, tb, dkeys, n, idx_bits, idx_bits + key_bits, stream));
+        if (idx_bits) HIP_TRY(rocprim::radix_sort_keys(st.temp.ptr, tb, dkeys, n, sort_lo, idx_bits + key_bits, stream));
         else HIP_TRY(rocprim::radix_sort_pairs<PairSortConfig>(st.temp.ptr, tb, dkeys, dvals, n, 0, key_bits, stream));
         keys = dkeys.current();
     }
     const uint32_t *vals = (own_sort && !idx_bits) ? own_vals : dvals.current();
+    build_trace(stream, "sort", n);
 
     if (direct) {
         const uint32_t idx_mask = (uint32_t)((1ull << idx_bits) - 1ull);
@@ -713,6 +723,7 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
         }
         PackOut pout{(float4 *)st.tri_pack.ptr, (float4 *)st.sphere_pack.ptr, (float4 *)st.quad_pack.ptr, (uint32_t *)st.sphere_ids.ptr,
                      (uint32_t *)st.quad_ids.ptr, (uint32_t *)st.tri_ids.ptr};
+        build_trace(stream, "kind ranks", mixed ? 1u : 0u);
         st.sorted_vals = nullptr;
         return build_wide_direct(stream, in, st, keys, idx_bits, mixed ? (const uint32_t *)st.rank_a.ptr : nullptr,
                                  mixed ? (const uint32_t *)st.rank_b.ptr : nullptr, pout, sort_error, err);

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <string>
+#include <vector>
 
 #include "build_internal.h"
 #include "bvh_common.h"
@@ -38,22 +39,31 @@ struct DwSplit {
 // works on one node and probes LANES positions per step: the searches over the millions of keys of a top-level node
 // are chains of dependent loads, 23 deep with one probe per step, 4 deep with 64.
 template <int LANES>
-__device__ __forceinline__ uint32_t dw_find_cut(const uint64_t *keys, uint32_t b, uint32_t e, uint32_t bit, uint32_t gl, uint32_t gbase) {
+__device__ __forceinline__ uint32_t dw_find_cut(const uint64_t *keys, uint32_t b, uint32_t e, uint32_t bit, uint32_t gl, uint32_t gbase, uint32_t *status) {
     uint32_t lo = b, hi = e - 1u;
+    // Both searches end after at most 32 steps on any input; the trip counter makes that a property of the code rather than
+    // of the keys (unsorted keys or a probe group with inactive lanes would otherwise spin): status bit 2 and a cut in the
+    // middle, which keeps the tree a tree; the host refuses it.
+    uint32_t trips = 0;
     if (LANES == 1) {
-        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if ((keys[mid] >> bit) & 1ull) hi = mid; else lo = mid; }
-        return hi;
+        while (hi - lo > 1u && trips++ < 40u) { const uint32_t mid = (lo + hi) >> 1; if ((keys[mid] >> bit) & 1ull) hi = mid; else lo = mid; }
+    } else {
+        while (hi - lo > 1u && hi < e && trips++ < 40u) {
+            const uint32_t step = (hi - lo + (uint32_t)LANES - 1u) / (uint32_t)LANES;
+            const uint32_t p = min(hi, lo + (gl + 1u) * step);                        // the group's last probe is hi itself
+            const bool set = ((keys[p] >> bit) & 1ull) != 0ull;
+            unsigned long long m = __ballot(set) >> gbase;
+            if (LANES < 64) m &= (1ull << LANES) - 1ull;
+            if (m == 0ull) { trips = 99u; break; }                                    // keys[hi] does not have the bit: not a sorted range
+            const uint32_t f = (uint32_t)__builtin_ctzll(m);
+            const uint32_t nlo = f ? lo + f * step : lo;                              // probe f - 1 had the bit clear, so it lies below hi
+            hi = min(hi, lo + (f + 1u) * step);
+            lo = nlo;
+        }
     }
-    while (hi - lo > 1u) {
-        const uint32_t step = (hi - lo + (uint32_t)LANES - 1u) / (uint32_t)LANES;
-        const uint32_t p = min(hi, lo + (gl + 1u) * step);                        // the group's last probe is hi itself
-        const bool set = ((keys[p] >> bit) & 1ull) != 0ull;
-        unsigned long long m = __ballot(set) >> gbase;
-        if (LANES < 64) m &= (1ull << LANES) - 1ull;
-        const uint32_t f = (uint32_t)__builtin_ctzll(m);
-        const uint32_t nlo = f ? lo + f * step : lo;                              // probe f - 1 had the bit clear, so it lies below hi
-        hi = min(hi, lo + (f + 1u) * step);
-        lo = nlo;
+    if (hi - lo > 1u || hi <= b || hi >= e) {
+        if (gl == 0u) atomicOr(status, 4u);
+        return (b + e) >> 1;
     }
     return hi;
 }
@@ -72,7 +82,10 @@ __device__ __forceinline__ void dw_split_node(const DwSplit &A, uint32_t level, 
     sb[0] = range.x; se[0] = range.y;
     int n = 1;
     const uint32_t size = range.y - range.x;
-    if (size <= 8u * A.leaf_max) {
+    if (size == 0u || range.y < range.x) {      // an entry nobody wrote: an empty node (every slot empty), and the build is refused
+        if (gl == 0u) atomicOr(&A.level_count[kWideMaxLevels + 2], 16u);
+        n = 0;
+    } else if (size <= 8u * A.leaf_max) {
         // Bottom node: every part is a leaf, so where exactly the cuts fall matters little (neighbours in Morton order
         // share a leaf either way): equal runs of ceil(size / 8) keys, no searches.  The slot of a run comes from the three
         // key bits of its first key below the range's common prefix (its octant inside the range's cell).
@@ -96,7 +109,7 @@ __device__ __forceinline__ void dw_split_node(const DwSplit &A, uint32_t level, 
             sd[k] = d;
         }
     }
-    while (n < 8 && size > 8u * A.leaf_max) {
+    while (n >= 1 && n < 8 && size > 8u * A.leaf_max && range.y > range.x) {
         uint32_t best = 0; int bk = -1;
 #pragma unroll
         for (int k = 0; k < 8; k++) { const uint32_t sz = se[k] - sb[k]; if (k < n && sz > A.leaf_max && sz > best) { best = sz; bk = k; } }
@@ -105,10 +118,11 @@ __device__ __forceinline__ void dw_split_node(const DwSplit &A, uint32_t level, 
 #pragma unroll
         for (int k = 1; k < 8; k++) if (k == bk) { b = sb[k]; e = se[k]; d = sd[k]; }
         const uint64_t first = A.keys[b], last = A.keys[e - 1];
-        const uint32_t bit = 63u - (uint32_t)__clzll((long long)(first ^ last));      // unique keys: first != last
+        const uint32_t bit = first != last ? 63u - (uint32_t)__clzll((long long)(first ^ last)) : 0u;      // unique keys: first != last
         uint32_t m = (b + e) >> 1, dl = d, dr = d;
-        if (bit >= A.idx_bits) {
-            m = dw_find_cut<LANES>(A.keys, b, e, bit, gl, gbase);
+        if (first >= last && gl == 0u) atomicOr(&A.level_count[kWideMaxLevels + 2], 8u);                    // (not sorted, or not unique: cut in the middle)
+        if (first < last && bit >= A.idx_bits) {
+            m = dw_find_cut<LANES>(A.keys, b, e, bit, gl, gbase, &A.level_count[kWideMaxLevels + 2]);
             const uint32_t ax = 2u - (bit - A.idx_bits) % 3u;      // code = ... x y z x y z: bit j of the code belongs to axis 2 - j % 3
             if (!((d >> (3u + ax)) & 1u)) { dl = d | (8u << ax); dr = dl | (1u << ax); }
         }
@@ -323,12 +337,28 @@ bool build_wide_direct(hipStream_t stream, const BuildInput &in, BuildState &st,
         uint32_t expect = 2;
         for (uint64_t cap = 8ull * S.leaf_max; cap < n; cap *= 8ull) expect++;
         const uint32_t chunk_end = std::min<uint32_t>(level == 0 ? expect + 1u : level + 4u, kWideMaxLevels);
-        for (; level < chunk_end; level++)
+        for (; level < chunk_end; level++) {
             hipLaunchKernelGGL(k_dw_split, dim3(grid), dim3(256), 0, stream, S, level, (const uint2 *)st.wide_queue[level & 1].ptr, (uint2 *)st.wide_queue[(level & 1) ^ 1].ptr, false);
+            build_trace(stream, "k_dw_split level", level);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(host_lc, lc, (kWideMaxLevels + 3) * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (host_lc[kWideMaxLevels + 2] & 2u) { err = "the key sort's look-back wait gave up"; return false; }
+        if (host_lc[kWideMaxLevels + 2] & 28u) {      // 4: a cut search did not converge, 8: a range whose first key is not below its last, 16: an empty range in the queue
+            err = "direct build: the sorted keys are not a strictly increasing sequence (status " + std::to_string(host_lc[kWideMaxLevels + 2]) + ")";
+            std::vector<uint64_t> hk(n);      // error path only: name the first offending position
+            if (hipMemcpy(hk.data(), keys, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                for (uint32_t i = 1; i < n; i++)
+                    if (hk[i - 1] >= hk[i]) {
+                        char buf[160];
+                        snprintf(buf, sizeof buf, ": keys[%u] = %016llx, keys[%u] = %016llx, idx_bits %u", i - 1, (unsigned long long)hk[i - 1], i, (unsigned long long)hk[i], idx_bits);
+                        err += buf;
+                        break;
+                    }
+            }
+            return false;
+        }
         if (host_lc[level] == 0) break;
         if (level >= kWideMaxLevels) { err = "wide BVH deeper than 64 levels"; return false; }
     }
@@ -336,8 +366,10 @@ bool build_wide_direct(hipStream_t stream, const BuildInput &in, BuildState &st,
     for (uint32_t l = 0; l <= kWideMaxLevels && host_lc[l]; l++) { st.n_wide += host_lc[l]; st.wide_levels = l + 1; st.direct_hint_lc[l] = host_lc[l]; }
     st.direct_hint_n = n; st.direct_hint_levels = st.wide_levels; st.direct_hint_leaf = S.leaf_max;
     st.counts_pending = false;
-    for (uint32_t l = st.wide_levels; l-- > 0;)
+    for (uint32_t l = st.wide_levels; l-- > 0;) {
         hipLaunchKernelGGL(k_dw_emit, dim3(std::min<uint32_t>((host_lc[l] + 31u) / 32u, 65536u)), dim3(256), 0, stream, E, (const uint32_t *)lc, l);
+        build_trace(stream, "k_dw_emit level", l);
+    }
     HIP_TRY(hipGetLastError());
     return true;
 }

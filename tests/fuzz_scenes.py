@@ -42,3 +42,31 @@ def random_scene(seed, w, h):
         pos = spheres["center"][0] + np.float32([0.01, 0.02, 0.0])                                        # the camera inside a sphere
     params["camera"] = abi.camera(tuple(pos), tuple(rs.uniform(-1, 1, 3)), float(rs.uniform(30, 80)), w / h, float(rs.choice([0.0, 1.0 / 45.0, 0.2])), float(rs.uniform(3, 9)))
     return abi.HostScene(spheres=spheres, quads=quads, tris=tris, materials=mats, textures=[tex], params=params, name=f"fuzz-{seed}")
+
+
+def random_soup(seed):
+    """A triangle soup of random size (a few hundred to ~80 k triangles) in random clusters of random spread, some spheres and
+    quads among them: tree SHAPES nobody chose (SAH tiers of one, two and three levels, lopsided groups, deep collapses)."""
+    rs = np.random.RandomState(50000 + seed)
+    n_t = int(np.exp(rs.uniform(np.log(200), np.log(80000))))
+    n_c = int(rs.randint(1, 40))
+    centres = rs.uniform(-20, 20, (n_c, 3)).astype(np.float32) * np.float32([1, 0.3, 1])
+    spread = np.exp(rs.uniform(np.log(0.05), np.log(6.0), n_c)).astype(np.float32)
+    size = np.exp(rs.uniform(np.log(0.01), np.log(1.5), n_c)).astype(np.float32)
+    k = rs.randint(0, n_c, n_t)
+    c = (centres[k] + rs.standard_normal((n_t, 3)).astype(np.float32) * spread[k, None]).astype(np.float32)
+    e = (rs.uniform(-1, 1, (2, n_t, 3)).astype(np.float32) * size[k, None]).astype(np.float32)
+    tris = np.zeros(n_t, abi.tri_dtype)
+    tris["v0"], tris["v1"], tris["v2"] = c, c + e[0], c + e[1]
+    if seed % 4 == 0:                                              # many copies of the same triangle: equal Morton codes, equal boxes
+        tris[: n_t // 3] = tris[0]
+    tris["materialIndex"] = 0
+    base = random_scene(seed, 64, 64)
+    n_s, n_q = (int(rs.randint(0, 40)), int(rs.randint(0, 20))) if seed % 2 else (0, 0)
+    spheres = np.zeros(n_s, abi.sphere_dtype)
+    spheres["center"] = rs.uniform(-20, 20, (n_s, 3)).astype(np.float32) * np.float32([1, 0.3, 1])
+    spheres["radius"] = rs.uniform(0.1, 3.0, n_s).astype(np.float32)
+    quads = np.zeros(n_q, abi.quad_dtype)
+    for i in range(n_q):
+        quads[i] = abi.make_quad(rs.uniform(-20, 20, 3) * [1, 0.3, 1], rs.uniform(-4, 4, 3), rs.uniform(-4, 4, 3), 0)[0]
+    return abi.HostScene(spheres=spheres, quads=quads, tris=tris, materials=base.materials, textures=base.textures, params=base.params, name=f"soup-{seed}")

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from computeraytracer_amd import abi
-from fuzz_scenes import random_scene
+from fuzz_scenes import random_scene, random_soup
 import oracle_lib as orc
 
 pytestmark = pytest.mark.gpu
@@ -217,3 +217,28 @@ def test_random_scenes_with_build_extensions(ctx, seed):
             assert np.array_equal(ctx.rays_query(rays, abi.QUERY_ANY)["id"] != abi.ID_MISS, hit), (flags, ext)
     finally:
         ctx.extensions_set(0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_soups_of_random_size_on_every_tree(ctx, seed):
+    # tree shapes nobody chose: a few hundred to ~80 k triangles in clusters of random spread (one, two or three SAH tiers,
+    # lopsided groups, duplicates), closest hits of 8192 random rays on every tree format against the oracle
+    scene = random_soup(seed)
+    rs = np.random.RandomState(seed)
+    n = 8192
+    rays = np.zeros(n, abi.ray_dtype)
+    rays["origin"] = (rs.uniform(-25, 25, (n, 3)) * np.float32([1, 0.3, 1])).astype(np.float32)
+    target = scene.tris["v0"][rs.randint(0, len(scene.tris), n)] + rs.standard_normal((n, 3)).astype(np.float32) * np.float32(0.5)
+    d = (target - rays["origin"]).astype(np.float32)
+    rays["direction"] = d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-20).astype(np.float32)
+    rays["t_max"] = np.inf
+    want = orc.hit_rays(scene, rays, flags=orc.TRAVERSE_FAST)
+    hit = want["id"] != abi.ID_MISS
+    assert hit.sum() > 100
+    ctx.configure(64, 64, tracer=abi.TRACER_WAVEFRONT)
+    ctx.upload(scene)
+    for name, flags, _ in TREES:
+        ctx.build(flags)
+        got = ctx.rays_query(rays, abi.QUERY_CLOSEST)
+        assert np.array_equal(got["id"], want["id"]), (name, len(scene.tris), int((got["id"] != want["id"]).sum()))
+        assert np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32)), name
