@@ -648,7 +648,11 @@ bool build_bvh(hipStream_t stream, const BuildInput &in, uint32_t flags, BuildSt
     // random soups of tests/test_gpu_fuzz.py: a direct build of a few thousand primitives got a valid but badly cut tree
     // (any partition of the primitives makes a correct BVH, which is why no parity test noticed), and now and then a cut
     // search that never ended.
+#ifdef CRT_REPRO_ROCPRIM_BIT_RANGE      // (to reproduce the finding: the trees stay valid, the build reports unsorted keys when a search notices)
+    const unsigned sort_lo = idx_bits;
+#else
     const unsigned sort_lo = (idx_bits && n <= (1u << 20)) ? 0u : idx_bits;
+#endif
     rocprim::double_buffer<uint64_t> dkeys((uint64_t *)st.keys.ptr, (uint64_t *)st.keys_alt.ptr);
     rocprim::double_buffer<uint32_t> dvals((uint32_t *)st.vals.ptr, (uint32_t *)st.vals_alt.ptr);
     if (direct && n >= (1u << 24)) { err = "wide BVH supports fewer than 2^24 primitives"; return false; }

@@ -672,7 +672,7 @@ bool patch_sah_links(hipStream_t stream, BuildState &st, std::string &err) {
     if (!measure_pair_depths(stream, st, err)) return false;
     const uint32_t limit = pair_depth_limit();
     if (st.pair_depth > limit) {
-        err = "SAH-refined tree is " + std::to_string(st.pair_depth) + " levels deep; the pair traversal stacks hold " + std::to_string(limit);
+        err = "SAH-refined tree is " + std::to_string(st.pair_depth) + " levels deep; the pair traversal stacks hold " + std::to_string(limit) + " (a scene with very many coincident primitives: build it without CRT_BVH_SAH_REFINE, the Morton tree is at most 95 levels deep)";
         return false;
     }
     return true;

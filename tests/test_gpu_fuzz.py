@@ -228,7 +228,9 @@ def test_random_soups_of_random_size_on_every_tree(ctx, seed):
     n = 8192
     rays = np.zeros(n, abi.ray_dtype)
     rays["origin"] = (rs.uniform(-25, 25, (n, 3)) * np.float32([1, 0.3, 1])).astype(np.float32)
-    target = scene.tris["v0"][rs.randint(0, len(scene.tris), n)] + rs.standard_normal((n, 3)).astype(np.float32) * np.float32(0.5)
+    pick = rs.randint(0, len(scene.tris), n)
+    centre = ((scene.tris["v0"][pick] + scene.tris["v1"][pick]) + scene.tris["v2"][pick]) / np.float32(3.0)
+    target = centre + rs.standard_normal((n, 3)).astype(np.float32) * np.where(rs.randint(0, 2, (n, 1)) == 0, np.float32(0.5), np.float32(0.0))
     d = (target - rays["origin"]).astype(np.float32)
     rays["direction"] = d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-20).astype(np.float32)
     rays["t_max"] = np.inf
@@ -238,7 +240,13 @@ def test_random_soups_of_random_size_on_every_tree(ctx, seed):
     ctx.configure(64, 64, tracer=abi.TRACER_WAVEFRONT)
     ctx.upload(scene)
     for name, flags, _ in TREES:
-        ctx.build(flags)
+        try:
+            ctx.build(flags)
+        except abi.CrtError as e:
+            # thousands of coincident triangles (the duplicates of every fourth soup) can make the SAH-refined tree deeper than
+            # the pair tracers' stacks; crt_bvh_build refuses such a tree and says so (test_deep_sah_tree_is_measured)
+            assert (flags & abi.BVH_SAH_REFINE) and "levels deep" in str(e), (name, str(e))
+            continue
         got = ctx.rays_query(rays, abi.QUERY_CLOSEST)
         assert np.array_equal(got["id"], want["id"]), (name, len(scene.tris), int((got["id"] != want["id"]).sum()))
         assert np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32)), name
