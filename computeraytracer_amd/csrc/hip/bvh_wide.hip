@@ -420,8 +420,10 @@ bool build_wide(hipStream_t stream, BuildState &st, std::string &err) {
             height_read = true;
             st.pair_depth = host_lc[kWideMaxLevels + 3] >> 21;
             if (st.pair_depth > pair_depth_limit()) {
-                err = "SAH-refined tree is " + std::to_string(st.pair_depth) + " levels deep; the pair traversal stacks hold " + std::to_string(pair_depth_limit()) + " (a scene with very many coincident primitives: build it without CRT_BVH_SAH_REFINE, the Morton tree is at most 95 levels deep)";
-                return false;
+                // Deeper than the pair tracers' stacks (a scene with very many coincident primitives).  The 8-wide tree, whose own
+                // depth is checked below, is what the wavefront tracer walks: it is kept, and the pair tree is withheld from
+                // the megakernel tracer and crt_bvh_read, as after a direct build or a refit.
+                st.pairs_valid = false;
             }
         }
         if (host_lc[level] == 0) break;

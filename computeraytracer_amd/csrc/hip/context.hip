@@ -298,7 +298,7 @@ int ready_to_render(crt_context *ctx) {
     if (!ctx->have_scene) return fail(ctx, CRT_ERR_INVALID, "crt_scene_upload has not been called");
     if (!ctx->have_bvh) return fail(ctx, CRT_ERR_INVALID, "crt_bvh_build has not been called for the current scene");
     if (!ctx->build.pairs_valid && ctx->cfg.tracer != CRT_TRACER_WAVEFRONT)
-        return fail(ctx, CRT_ERR_INVALID, "a CRT_BVH_WIDE_DIRECT build has no pair BVH: the megakernel tracer cannot render it (configure CRT_TRACER_WAVEFRONT)");
+        return fail(ctx, CRT_ERR_INVALID, "no pair BVH for the megakernel tracer (a CRT_BVH_WIDE_DIRECT build has none, a refit leaves it stale, a SAH-refined tree deeper than its stacks is withheld): configure CRT_TRACER_WAVEFRONT");
     return CRT_OK;
 }
 

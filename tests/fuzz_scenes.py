@@ -70,3 +70,25 @@ def random_soup(seed):
     for i in range(n_q):
         quads[i] = abi.make_quad(rs.uniform(-20, 20, 3) * [1, 0.3, 1], rs.uniform(-4, 4, 3), rs.uniform(-4, 4, 3), 0)[0]
     return abi.HostScene(spheres=spheres, quads=quads, tris=tris, materials=base.materials, textures=base.textures, params=base.params, name=f"soup-{seed}")
+
+
+def soup_rays(scene, seed, n):
+    rs = np.random.RandomState(seed)
+    rays = np.zeros(n, abi.ray_dtype)
+    # Every ray is aimed at (or near) the centre of a random triangle from an origin 10 to 300 triangle sizes away.  Origins
+    # thousands of sizes away are avoided on purpose: the shader's determinant test has an ABSOLUTE threshold, so a tiny
+    # triangle seen from far away at a shallow angle has barycentrics that are rounding noise, "hits" can lie outside the
+    # triangle's box and then depend on the tree (the first version of this test met three such rays in
+    # 2 x 10^7, each among exact duplicates, where the tie-break makes them visible).
+    pick = rs.randint(0, len(scene.tris), n)
+    tv = scene.tris[pick]
+    centre = ((tv["v0"] + tv["v1"]) + tv["v2"]) / np.float32(3.0)
+    size = np.maximum(np.linalg.norm(tv["v1"] - tv["v0"], axis=1), np.linalg.norm(tv["v2"] - tv["v0"], axis=1))[:, None].astype(np.float32)
+    target = centre + rs.standard_normal((n, 3)).astype(np.float32) * size * np.where(rs.randint(0, 2, (n, 1)) == 0, np.float32(2.0), np.float32(0.0))
+    dirn = rs.standard_normal((n, 3)).astype(np.float32)
+    dirn /= np.linalg.norm(dirn, axis=1, keepdims=True).astype(np.float32)
+    rays["origin"] = (target - dirn * size * np.exp(rs.uniform(np.log(10.0), np.log(300.0), (n, 1))).astype(np.float32)).astype(np.float32)
+    d = (target - rays["origin"]).astype(np.float32)
+    rays["direction"] = d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-20).astype(np.float32)
+    rays["t_max"] = np.inf
+    return rays

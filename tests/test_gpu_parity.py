@@ -777,9 +777,21 @@ def test_deep_sah_tree_is_measured(ctx, monkeypatch):
         ctx.build(abi.BVH_SAH_REFINE)
     with pytest.raises(abi.CrtError, match="crt_bvh_build has not been called"):
         ctx.dispatch(scene.params)
-    # the 8-wide build learns the height from the collapse table that k_sah_group makes (no depth pass of its own)
-    with pytest.raises(abi.CrtError, match="levels deep"):
-        ctx.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE)
+    # the 8-wide build learns the height from the collapse table that k_sah_group makes (no depth pass of its own).  Its
+    # own tree is what the wavefront tracer walks, so the build stands; only the pair tree is withheld (megakernel
+    # tracer, crt_bvh_read), as after a direct build
+    ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+    ctx.upload(scene)
+    ctx.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE)
+    ps2, seeds2 = _params(scene, 2)
+    ctx.render(ps2[0], 1, seeds2); ctx.sync()
+    assert np.array_equal(ctx.hit_ids(), ref[1]) and np.array_equal(ctx.image().view(np.uint32), ref[0].view(np.uint32))
+    assert len(ctx.bvh()[0]) == 0
+    ctx.configure(w, h, tracer=abi.TRACER_MEGAKERNEL)
+    ctx.upload(scene)
+    ctx.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE)
+    with pytest.raises(abi.CrtError, match="no pair BVH for the megakernel tracer"):
+        ctx.dispatch(scene.params)
     monkeypatch.delenv("CRT_BVH_MAX_PAIR_DEPTH")
     ctx.build(abi.BVH_SAH_REFINE)
 
