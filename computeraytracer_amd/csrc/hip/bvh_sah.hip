@@ -263,7 +263,12 @@ __device__ void sah_wave_subtree(const SahGroupArgs &g, SahLds &L, uint32_t grou
             if (cost < best) { best = cost; best_ax = (uint32_t)ax; }
         }
         // cheapest candidate of the segment: inclusive min-scan, read at the segment's last lane
-        uint32_t bk_hi = __float_as_uint(best), bk_lo = (best_ax << 8) | lane;
+        // Ties go to the most balanced cut.  (Coincident primitives price every cut of a segment alike; lowest lane first
+        // peeled ONE item per level, and thousands of copies of one triangle made trees a hundred levels deep, which the
+        // pair tracers' stacks and the 8-wide format's 64 levels then refused: found by the random soups.)
+        const uint32_t cand_l = lane - s0 + 1u, cand_r = s1 - lane - 1u;
+        const uint32_t imbalance = (cand_l > cand_r ? cand_l - cand_r : cand_r - cand_l) & 0x7Fu;
+        uint32_t bk_hi = __float_as_uint(best), bk_lo = (imbalance << 16) | (best_ax << 8) | lane;
         seg_scan_min64(bk_hi, bk_lo, lane, s0);
         const unsigned long long bk = ((unsigned long long)(uint32_t)__shfl((int)bk_hi, (int)(s1 - 1u)) << 32) | (uint32_t)__shfl((int)bk_lo, (int)(s1 - 1u));
         const float split_cost = __uint_as_float((uint32_t)(bk >> 32));
