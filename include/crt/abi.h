@@ -111,7 +111,9 @@ int crt_tris_animate(crt_context *ctx, float frame, float amplitude);
 
 /* Replaces one frame of VulkanEngine::draw (vk_engine.cpp:1409-1435): the
  * 112-byte UBO write + vkCmdDispatch(W/8, H/8, 1).  One sample per pixel;
- * params->camera.iteration == 1 resets the accumulation (compute.comp:474). */
+ * params->camera.iteration == 1 resets the accumulation (compute.comp:474), by the shader's own arithmetic:
+ * cum + ((-cum) + pass), which equals pass up to one rounding when cum holds an earlier picture; crt_configure zeroes
+ * the image exactly. */
 int crt_dispatch(crt_context *ctx, const crt_scene_params *params);
 
 /* n dispatches enqueued back to back: dispatch i uses *params with

@@ -242,3 +242,54 @@ def test_random_soups_of_random_size_on_every_tree(ctx, seed):
         got = ctx.rays_query(rays, abi.QUERY_CLOSEST)
         assert np.array_equal(got["id"], want["id"]), (name, len(scene.tris), int((got["id"] != want["id"]).sum()))
         assert np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32)), name
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_soups_rendered_animated_and_refitted(ctx, seed):
+    # paths (not only queries) through trees of random shape: a soup of up to ~30 k triangles with random materials, a camera
+    # that looks at one of its triangles, three tree / tracer pairs; then crt_tris_animate, a refit of the 8-wide tree and a
+    # direct rebuild, against the oracle on the triangles read back from the device
+    rs = np.random.RandomState(4000 + seed)
+    scene = random_soup(seed)
+    if len(scene.tris) > 30000:
+        scene = abi.HostScene(spheres=scene.spheres, quads=scene.quads, tris=scene.tris[:30000], materials=scene.materials, textures=scene.textures, params=scene.params)
+    tris = scene.tris.copy()
+    tris["materialIndex"] = rs.randint(0, len(scene.materials), len(tris))
+    tris["u"] = rs.uniform(-1, 2, (len(tris), 3)).astype(np.float32); tris["v"] = rs.uniform(-1, 2, (len(tris), 3)).astype(np.float32)
+    w, h = 48, 32
+    k = int(rs.randint(0, len(tris)))
+    at = tris["v0"][k]
+    size = float(max(np.linalg.norm(tris["v1"][k] - tris["v0"][k]), 1e-3))
+    d = rs.standard_normal(3); d /= np.linalg.norm(d)
+    pos = at + d * size * float(np.exp(rs.uniform(np.log(5.0), np.log(200.0))))
+    params = scene.params.copy()
+    params["camera"] = abi.camera(tuple(pos), tuple(at), float(rs.uniform(20, 90)), w / h, 0.0, 10.0)
+    scene = abi.HostScene(spheres=scene.spheres, quads=scene.quads, tris=tris, materials=scene.materials, textures=scene.textures, params=params)
+    seeds = abi.frame_seeds(0, 2)
+    ps = [scene.params_for(i + 1, seeds[i]) for i in range(2)]
+    ref_img, ref_ids, _ = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_FAST)
+    for flags, tracer in [(abi.BVH_SAH_REFINE | abi.BVH_WIDE, abi.TRACER_WAVEFRONT), (abi.BVH_LBVH, abi.TRACER_MEGAKERNEL), (abi.BVH_WIDE_DIRECT, abi.TRACER_WAVEFRONT)]:
+        ctx.configure(w, h, tracer=tracer)
+        ctx.upload(scene)
+        ctx.build(flags)
+        ctx.render(ps[0], 1, seeds); ctx.sync()
+        assert np.array_equal(ctx.hit_ids(), ref_ids), (flags, tracer, len(tris))
+        assert np.array_equal(ctx.image().view(np.uint32), ref_img.view(np.uint32)), (flags, tracer, len(tris))
+    # animate on the device, refit / rebuild, render; the oracle gets the moved triangles
+    ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+    ctx.upload(scene)
+    ctx.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE)
+    ctx.animate(float(seed) + 0.5, 0.25 * size)
+    moved = abi.HostScene(spheres=scene.spheres, quads=scene.quads, tris=ctx.tris_read(), materials=scene.materials, textures=scene.textures, params=params)
+    ref2, ids2, _ = orc.render(moved, ps, w, h, flags=orc.TRAVERSE_FAST)
+    for how in ("refit", "rebuild"):
+        if how == "refit":
+            ctx.refit()
+        else:
+            # crt_configure zeroes the image (and keeps the scene): iteration 1 "resets" by the shader's arithmetic, cum + (-cum + pass)
+            # (compute.comp:474), which equals pass only up to one rounding when cum holds an earlier picture
+            ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+            ctx.build(abi.BVH_WIDE_DIRECT)
+        ctx.render(ps[0], 1, seeds); ctx.sync()
+        assert np.array_equal(ctx.hit_ids(), ids2), (how, len(tris))
+        assert np.array_equal(ctx.image().view(np.uint32), ref2.view(np.uint32)), (how, len(tris))
