@@ -219,6 +219,14 @@ def test_random_scenes_with_build_extensions(ctx, seed):
         ctx.extensions_set(0)
 
 
+def _grazes(scene, rays, i, hid):
+    if hid == abi.ID_MISS or (int(hid) >> 30) != abi.KIND_TRI:
+        return False
+    tr = scene.tris[int(hid) & 0x3FFFFFFF]
+    c = np.cross((tr["v1"] - tr["v0"]).astype(np.float64), (tr["v2"] - tr["v0"]).astype(np.float64))
+    return abs(float(np.dot(rays["direction"][i].astype(np.float64), c))) < 1e-3 * float(np.linalg.norm(c))
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_soups_of_random_size_on_every_tree(ctx, seed):
     # tree shapes nobody chose: a few hundred to ~80 k triangles in clusters of random spread (one, two or three SAH tiers,
@@ -240,8 +248,12 @@ def test_random_soups_of_random_size_on_every_tree(ctx, seed):
             assert flags == abi.BVH_SAH_REFINE and "levels deep" in str(e), (name, str(e))      # (not seen again since SAH ties go to the balanced cut)
             continue
         got = ctx.rays_query(rays, abi.QUERY_CLOSEST)
-        assert np.array_equal(got["id"], want["id"]), (name, len(scene.tris), int((got["id"] != want["id"]).sum()))
-        assert np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32)), name
+        bad = np.nonzero((got["id"] != want["id"]) | (hit & (got["t"].view(np.uint32) != want["t"].view(np.uint32))))[0]
+        # A ray that lies IN the plane of a triangle (|cos(ray, normal)| < 1e-3) has a determinant of rounding-noise size; whether
+        # it "hits" is then decided by noise, at a distance that need not lie inside the triangle's box, and so by the tree
+        # ("what remains").  About one aimed ray in 3 x 10^7 is such a ray; they are excused, nothing else is.
+        real = [int(i) for i in bad if not (_grazes(scene, rays, i, got["id"][i]) or _grazes(scene, rays, i, want["id"][i]))]
+        assert not real and len(bad) <= 2, (name, len(scene.tris), real[:4], len(bad))
 
 
 @pytest.mark.parametrize("seed", range(6))
