@@ -305,3 +305,49 @@ def test_random_soups_rendered_animated_and_refitted(ctx, seed):
         ctx.render(ps[0], 1, seeds); ctx.sync()
         assert np.array_equal(ctx.hit_ids(), ids2), (how, len(tris))
         assert np.array_equal(ctx.image().view(np.uint32), ref2.view(np.uint32)), (how, len(tris))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_soups_rebuilt_without_waiting(ctx, seed):
+    # the per-frame path (crt_tris_animate -> crt_bvh_build(build_ms = NULL) -> crt_render, nothing waits) on soups whose
+    # animation is LARGE against the triangles (the tree's shape and depth change from frame to frame): every frame is either
+    # identical to the oracle on the read-back triangles, or reported as "deeper than planned" by the next blocking call, in
+    # which case a waiting rebuild follows and must be identical
+    rs = np.random.RandomState(8000 + seed)
+    scene = random_soup(200 + seed)
+    keep = min(len(scene.tris), 20000)
+    tris = scene.tris[:keep].copy()
+    scene = abi.HostScene(spheres=scene.spheres[:0], quads=scene.quads[:0], tris=tris, materials=scene.materials, textures=scene.textures, params=scene.params)
+    w, h = 40, 32
+    k = int(rs.randint(0, len(tris)))
+    at = tris["v0"][k]
+    size = float(max(np.linalg.norm(tris["v1"][k] - tris["v0"][k]), 1e-3))
+    d = rs.standard_normal(3); d /= np.linalg.norm(d)
+    params = scene.params.copy()
+    params["camera"] = abi.camera(tuple(at + d * size * 60.0), tuple(at), 60.0, w / h, 0.0, 10.0)
+    scene = abi.HostScene(spheres=scene.spheres, quads=scene.quads, tris=tris, materials=scene.materials, textures=scene.textures, params=params)
+    seeds = abi.frame_seeds(0, 1)
+    p = scene.params_for(1, seeds[0])
+    ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+    ctx.upload(scene)
+    ctx.build(abi.BVH_WIDE_DIRECT)
+    overflows = 0
+    for frame in range(1, 6):
+        amp = float(size * np.exp(rs.uniform(np.log(0.1), np.log(300.0))))
+        ctx.animate(float(frame) * 0.7, amp)
+        ctx.build(abi.BVH_WIDE_DIRECT, wait=False)
+        ctx.render(p, 1, seeds)
+        try:
+            ctx.sync()
+        except abi.CrtError as e:
+            assert "crt_bvh_build again" in str(e), str(e)
+            overflows += 1
+            ctx.build(abi.BVH_WIDE_DIRECT)
+            ctx.render(p, 1, seeds); ctx.sync()
+        moved = abi.HostScene(spheres=scene.spheres, quads=scene.quads, tris=ctx.tris_read(), materials=scene.materials, textures=scene.textures, params=params)
+        ref, rids, _ = orc.render(moved, [p], w, h, flags=orc.TRAVERSE_FAST)
+        assert np.array_equal(ctx.hit_ids(), rids), (frame, len(tris), overflows)
+        # iteration 1 restarts the picture by the shader's arithmetic (cum + (-cum + pass)): compare through a fresh image
+        ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+        ctx.render(p, 1, seeds); ctx.sync()
+        assert np.array_equal(ctx.image().view(np.uint32), ref.view(np.uint32)), (frame, len(tris), overflows)
