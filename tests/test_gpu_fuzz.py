@@ -351,3 +351,35 @@ def test_random_soups_rebuilt_without_waiting(ctx, seed):
         ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
         ctx.render(p, 1, seeds); ctx.sync()
         assert np.array_equal(ctx.image().view(np.uint32), ref.view(np.uint32)), (frame, len(tris), overflows)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_texture_sizes(ctx, seed):
+    # textures of odd sizes (1 x 1, one texel wide or high, non powers of two) behind negative and > 1 coordinates, with and
+    # without the per-material texture index; every Lambertian of the scene is textured
+    rs = np.random.RandomState(600 + seed)
+    w, h = 56, 40
+    scene = random_scene(900 + seed, w, h)
+    sizes = [(1, 1), (1, 7), (5, 1), (3, 5), (64, 2), (255, 3), (17, 33)]
+    texs = []
+    for _ in range(3):
+        th, tw = sizes[int(rs.randint(0, len(sizes)))]
+        texs.append(rs.randint(0, 256, (th, tw, 4)).astype(np.uint8))
+    mats = scene.materials.copy()
+    mats["textureIndex"] = np.where(mats["type"] == abi.MAT_LAMBERTIAN, rs.randint(0, 3, len(mats)), 0xFFFFFFFF)
+    scene = abi.HostScene(spheres=scene.spheres, quads=scene.quads, tris=scene.tris, materials=mats, textures=texs, params=scene.params)
+    seeds = abi.frame_seeds(0, 3)
+    ps = [scene.params_for(i + 1, seeds[i]) for i in range(3)]
+    try:
+        for ext, oext in ((0, 0), (abi.EXT_TEXTURE_INDEX, orc.EXT_TEXTURE_INDEX), (abi.EXT_TEXTURE_INDEX | abi.EXT_ALPHA_TEST, orc.EXT_TEXTURE_INDEX | orc.EXT_ALPHA_TEST)):
+            ref_img, ref_ids, _ = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_BRUTE | oext)
+            for flags, tracer in [(abi.BVH_SAH_REFINE | abi.BVH_WIDE, abi.TRACER_WAVEFRONT), (abi.BVH_LBVH, abi.TRACER_MEGAKERNEL)]:
+                ctx.configure(w, h, tracer=tracer)
+                ctx.extensions_set(ext)
+                ctx.upload(scene)
+                ctx.build(flags)
+                ctx.render(ps[0], 1, seeds); ctx.sync()
+                assert np.array_equal(ctx.hit_ids(), ref_ids), (ext, tracer, [t.shape for t in texs])
+                assert np.array_equal(ctx.image().view(np.uint32), ref_img.view(np.uint32)), (ext, tracer, [t.shape for t in texs])
+    finally:
+        ctx.extensions_set(0)
