@@ -383,3 +383,42 @@ def test_random_texture_sizes(ctx, seed):
                 assert np.array_equal(ctx.image().view(np.uint32), ref_img.view(np.uint32)), (ext, tracer, [t.shape for t in texs])
     finally:
         ctx.extensions_set(0)
+
+
+def _scaled(scene, k, shift):
+    """The scene multiplied by k and moved by shift (quads rebuilt through crt_quad_init, so that their derived fields fit)."""
+    k = np.float32(k); shift = np.asarray(shift, np.float32)
+    sp = scene.spheres.copy(); sp["center"] = sp["center"] * k + shift; sp["radius"] = sp["radius"] * k
+    qs = scene.quads.copy()
+    for i in range(len(qs)):
+        qs[i] = abi.make_quad(qs["corner"][i] * k + shift, qs["u"][i] * k, qs["v"][i] * k, int(qs["materialIndex"][i]))[0]
+    tr = scene.tris.copy()
+    for f in ("v0", "v1", "v2"):
+        tr[f] = tr[f] * k + shift
+    return abi.HostScene(spheres=sp, quads=qs, tris=tr, materials=scene.materials, textures=scene.textures, params=scene.params)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scenes_at_random_scales_and_offsets(ctx, seed):
+    # the same random scenes a hundred times smaller to a hundred thousand times larger, and moved away from the origin by up
+    # to a thousand scene sizes (coordinates then carry only a few significant bits of detail: boxes, Morton grid and the
+    # conservative slab test must still contain what the primitive tests accept)
+    rs = np.random.RandomState(1200 + seed)
+    k = float(np.exp(rs.uniform(np.log(1e-2), np.log(1e5))))
+    shift = rs.uniform(-1, 1, 3) * 8.0 * k * float(np.exp(rs.uniform(np.log(1e-2), np.log(1e3))))
+    scene = _scaled(random_scene(1300 + seed, 64, 64), k, shift)
+    n = 8192
+    rays = np.zeros(n, abi.ray_dtype)
+    rays["origin"] = ((rs.uniform(-8, 8, (n, 3)) * [1, 0.4, 1]) * k + shift).astype(np.float32)
+    d = rs.standard_normal((n, 3)).astype(np.float32)
+    rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    rays["t_max"] = np.inf
+    want = orc.hit_rays(scene, rays)
+    hit = want["id"] != abi.ID_MISS
+    ctx.configure(64, 64, tracer=abi.TRACER_WAVEFRONT)
+    ctx.upload(scene)
+    for name, flags, _ in TREES:
+        ctx.build(flags)
+        got = ctx.rays_query(rays, abi.QUERY_CLOSEST)
+        assert np.array_equal(got["id"], want["id"]), (name, k, int((got["id"] != want["id"]).sum()))
+        assert np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32)), (name, k)
