@@ -40,5 +40,28 @@ int main() {
             CK(hipFree(a)); CK(hipFree(b));
         }
     }
+    // (code, index) PAIRS over bits [0, 63): the static builds' sort
+    for (unsigned n : sizes) {
+        std::vector<unsigned long long> h(n); std::vector<unsigned> hv(n);
+        unsigned long long s = 1234567ull + n;
+        for (unsigned i = 0; i < n; i++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = (s >> 1) >> (i % 3 ? 0 : 40); hv[i] = i; }      // a third of the keys collide in 23 bits
+        unsigned long long *a, *b; unsigned *va, *vb; void *tmp = nullptr; size_t tb = 0;
+        CK(hipMalloc(&a, n * 8ull)); CK(hipMalloc(&b, n * 8ull)); CK(hipMalloc(&va, n * 4ull)); CK(hipMalloc(&vb, n * 4ull));
+        CK(hipMemcpy(a, h.data(), n * 8ull, hipMemcpyHostToDevice)); CK(hipMemcpy(va, hv.data(), n * 4ull, hipMemcpyHostToDevice));
+        rocprim::double_buffer<unsigned long long> d(a, b); rocprim::double_buffer<unsigned> dv(va, vb);
+        CK(rocprim::radix_sort_pairs(nullptr, tb, d, dv, n, 0u, 63u, 0));
+        CK(hipMalloc(&tmp, tb));
+        CK(rocprim::radix_sort_pairs(tmp, tb, d, dv, n, 0u, 63u, 0));
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> r(n); std::vector<unsigned> rv(n);
+        CK(hipMemcpy(r.data(), d.current(), n * 8ull, hipMemcpyDeviceToHost)); CK(hipMemcpy(rv.data(), dv.current(), n * 4ull, hipMemcpyDeviceToHost));
+        unsigned bad = 0;
+        for (unsigned i = 0; i < n; i++) {
+            if (rv[i] >= n || h[rv[i]] != r[i]) bad++;                                   // the value travelled with its key
+            if (i && (r[i - 1] > r[i] || (r[i - 1] == r[i] && rv[i - 1] > rv[i]))) bad++;   // sorted, and stable
+        }
+        printf("pairs [ 0,63) n %7u: %s\n", n, bad ? "NOT SORTED / NOT STABLE" : "sorted, stable");
+        CK(hipFree(tmp)); CK(hipFree(a)); CK(hipFree(b)); CK(hipFree(va)); CK(hipFree(vb));
+    }
     return 0;
 }
