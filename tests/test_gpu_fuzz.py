@@ -429,3 +429,44 @@ def test_random_scenes_at_random_scales_and_offsets(ctx, seed):
         got = ctx.rays_query(rays, abi.QUERY_CLOSEST)
         assert np.array_equal(got["id"], want["id"]), (name, k, int((got["id"] != want["id"]).sum()))
         assert np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32)), (name, k)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_partial_triangle_updates(ctx, seed):
+    # crt_tris_update on random sub-ranges (first > 0, single triangles, the last one, everything), several in a row, then a
+    # refit or a rebuild; the oracle renders the scene with the same ranges replaced
+    rs = np.random.RandomState(2100 + seed)
+    w, h = 48, 40
+    scene = random_scene(2200 + seed, w, h)
+    if len(scene.tris) < 4:
+        return
+    seeds = abi.frame_seeds(0, 2)
+    ps = [scene.params_for(i + 1, seeds[i]) for i in range(2)]
+    ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+    ctx.upload(scene)
+    ctx.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE)
+    tris = scene.tris.copy()
+    n = len(tris)
+    for step in range(4):
+        kind = int(rs.randint(0, 4))
+        first, count = [(int(rs.randint(0, n)), 1), (n - 1, 1), (0, n), (int(rs.randint(0, n // 2)), int(rs.randint(1, n // 2 + 1)))][kind]
+        count = min(count, n - first)
+        new = tris[first:first + count].copy()
+        shift = rs.uniform(-0.4, 0.4, (count, 3)).astype(np.float32)
+        for f in ("v0", "v1", "v2"):
+            new[f] = new[f] + shift
+        new["materialIndex"] = rs.randint(0, len(scene.materials), count)
+        tris[first:first + count] = new
+        ctx.tris_update(new, first)
+    np.testing.assert_array_equal(ctx.tris_read(), tris)
+    moved = abi.HostScene(spheres=scene.spheres, quads=scene.quads, tris=tris, materials=scene.materials, textures=scene.textures, params=scene.params)
+    ref, rids, _ = orc.render(moved, ps, w, h, flags=orc.TRAVERSE_BRUTE)
+    for how in ("refit", "rebuild", "direct"):
+        ctx.configure(w, h, tracer=abi.TRACER_WAVEFRONT)
+        if how == "refit":
+            ctx.refit()
+        else:
+            ctx.build(abi.BVH_SAH_REFINE | abi.BVH_WIDE if how == "rebuild" else abi.BVH_WIDE_DIRECT)
+        ctx.render(ps[0], 1, seeds); ctx.sync()
+        assert np.array_equal(ctx.hit_ids(), rids), how
+        assert np.array_equal(ctx.image().view(np.uint32), ref.view(np.uint32)), how
