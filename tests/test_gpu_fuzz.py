@@ -531,3 +531,54 @@ def test_random_scenes_with_nan_and_infinity_in_the_primitives(ctx, seed):
             got = ctx.rays_query(rays, abi.QUERY_CLOSEST)
             if nan_only:
                 assert np.array_equal(got["id"], want["id"]) and np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32)), name
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_degenerate_rays(ctx, seed):
+    # rays nobody aims on purpose: axis-aligned and planar directions (exact zeros: 1 / d = inf, 0 * inf = NaN in a slab
+    # test), unnormalised and tiny directions, origins exactly on primitive vertices, t_max zero, negative, denormal, NaN;
+    # NaN and infinite origins and directions.  Closest and any hit against the exhaustive test on every tree.
+    rs = np.random.RandomState(5100 + seed)
+    scene = random_scene(5200 + seed, 64, 64)
+    n = 8192
+    rays = np.zeros(n, abi.ray_dtype)
+    o = (rs.uniform(-8, 8, (n, 3)) * np.float32([1, 0.4, 1])).astype(np.float32)
+    d = rs.standard_normal((n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    kind = rs.randint(0, 8, n)
+    ax = rs.randint(0, 3, n)
+    for a in range(3):
+        d[(kind == 0) & (ax != a), a] = 0.0                         # axis-aligned: two exact zeros
+        d[(kind == 1) & (ax == a), a] = 0.0                         # planar: one exact zero
+    m = (kind == 0) | (kind == 1)
+    d[m] /= np.maximum(np.linalg.norm(d[m], axis=1, keepdims=True), 1e-30).astype(np.float32)
+    d[kind == 2] *= np.float32(1e-20)                                # tiny, unnormalised: outside the contract (crt_ray.direction is unit
+    d[kind == 3] *= np.float32(1e6)                                  # length, hit_sphere relies on it); must complete, is not compared
+    cmp = (kind != 2) & (kind != 3)
+    if len(scene.tris):
+        m = kind == 4                                                # origin exactly on a vertex
+        o[m] = scene.tris["v0"][rs.randint(0, len(scene.tris), int(m.sum()))]
+    poison = np.array([np.nan, np.inf, -np.inf, 0.0], np.float32)
+    # (origins get NaN or 0 only: from an infinite origin a triangle's t comes out as +inf, which the inclusive interval rule
+    # (t_near, t_max] accepts as a "hit" at t_max = inf on the lowest ID tested, i.e. an answer that depends on the tree)
+    m = np.nonzero(kind == 5)[0]
+    o[m, rs.randint(0, 3, len(m))] = np.array([np.nan, 0.0], np.float32)[rs.randint(0, 2, len(m))]
+    m = np.nonzero(kind == 6)[0]
+    pv = poison[rs.randint(0, 4, len(m))]
+    d[m, rs.randint(0, 3, len(m))] = pv
+    cmp[m[~np.isnan(pv)]] = False                                    # an infinite or zeroed component: not a unit direction either
+    rays["origin"], rays["direction"] = o, d
+    rays["t_max"] = np.inf
+    m = np.nonzero(kind == 7)[0]
+    rays["t_max"][m] = np.array([0.0, -1.0, 1e-42, np.nan, 0.001, 0.0010001, 3e38], np.float32)[rs.randint(0, 7, len(m))]
+    want = orc.hit_rays(scene, rays)
+    hit = want["id"] != abi.ID_MISS
+    ctx.configure(64, 64, tracer=abi.TRACER_WAVEFRONT)
+    ctx.upload(scene)
+    for name, flags, _ in TREES:
+        ctx.build(flags)
+        got = ctx.rays_query(rays, abi.QUERY_CLOSEST)
+        bad = np.nonzero(cmp & ((got["id"] != want["id"]) | (hit & (got["t"].view(np.uint32) != want["t"].view(np.uint32)))))[0]
+        assert len(bad) == 0, (name, len(bad), [(int(i), int(kind[i])) for i in bad[:6]])
+        anyhit = ctx.rays_query(rays, abi.QUERY_ANY)
+        assert np.array_equal((anyhit["id"] != abi.ID_MISS)[cmp], hit[cmp]), name
