@@ -62,7 +62,10 @@ int crt_scene_upload(crt_context *ctx, const crt_scene_desc *scene);
 /* Limits (every one is checked and reported as an error, never a wrong image): fewer than 2^30 primitives of a kind
  * (ID tag), width x height below 2^31; the wavefront tracer and crt_rays_query take up to 2^26 - 2 primitives and
  * 16 bounces; CRT_BVH_WIDE up to 2^24 - 1 primitives and 64 levels; a wavefront batch needs fewer than 2^26 - 1
- * pixels per context (larger frames render one iteration per launch sequence). */
+ * pixels per context (larger frames render one iteration per launch sequence).  A CRT_BVH_SAH_REFINE pair tree deeper than
+ * the pair tracers' stacks (96 levels; only scenes with thousands of coincident primitives come near) fails the build when
+ * it is the only tree; with CRT_BVH_WIDE the build stands and the pair tree is withheld from the megakernel tracer and
+ * crt_bvh_read, as after CRT_BVH_WIDE_DIRECT or a refit. */
 
 /* Build extensions (CRT_EXT_* of types.h).  No counterpart in the reference: its shader ignores
  * RTMaterial::GPU_t::textureIndex (compute.comp:386-387 reads textures[0]) and has no alpha test; SURVEY section 7
