@@ -582,3 +582,41 @@ def test_random_degenerate_rays(ctx, seed):
         assert len(bad) == 0, (name, len(bad), [(int(i), int(kind[i])) for i in bad[:6]])
         anyhit = ctx.rays_query(rays, abi.QUERY_ANY)
         assert np.array_equal((anyhit["id"] != abi.ID_MISS)[cmp], hit[cmp]), name
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_two_contexts_interleaved_on_one_gpu(seed):
+    # two contexts of one process on one GPU, different scenes, sizes, trees and tracers, their calls interleaved without
+    # waiting in between: nothing of one may leak into the other (static device state, cached launch plans, queues)
+    rs = np.random.RandomState(6100 + seed)
+    a, b = abi.Context(0), abi.Context(0)
+    try:
+        cfgs = []
+        for c, k in ((a, 0), (b, 1)):
+            w, h = int(rs.randint(16, 80)), int(rs.randint(16, 64))
+            scene = random_scene(6200 + 2 * seed + k, w, h) if (seed + k) % 2 == 0 else random_soup(300 + 2 * seed + k)
+            if len(scene.tris) > 20000:
+                scene = abi.HostScene(spheres=scene.spheres, quads=scene.quads, tris=scene.tris[:20000], materials=scene.materials, textures=scene.textures, params=scene.params)
+            flags, tracer = [(abi.BVH_SAH_REFINE | abi.BVH_WIDE, abi.TRACER_WAVEFRONT), (abi.BVH_LBVH, abi.TRACER_MEGAKERNEL), (abi.BVH_WIDE_DIRECT, abi.TRACER_WAVEFRONT)][int(rs.randint(0, 3))]
+            n = int(rs.randint(1, 4))
+            seeds = abi.frame_seeds(0, n)
+            ps = [scene.params_for(i + 1, seeds[i]) for i in range(n)]
+            cfgs.append((c, scene, w, h, flags, tracer, seeds, ps))
+        for c, scene, w, h, flags, tracer, seeds, ps in cfgs:
+            c.configure(w, h, tracer=tracer)
+        for c, scene, w, h, flags, tracer, seeds, ps in cfgs:
+            c.upload(scene)
+        for c, scene, w, h, flags, tracer, seeds, ps in cfgs:
+            c.build(flags)
+        for rep in range(2):                                   # the second round restarts the picture: fresh images first
+            for c, scene, w, h, flags, tracer, seeds, ps in cfgs:
+                c.configure(w, h, tracer=tracer)
+            for c, scene, w, h, flags, tracer, seeds, ps in cfgs:
+                c.render(ps[0], 1, seeds)                      # enqueued on both contexts before anybody waits
+            for c, scene, w, h, flags, tracer, seeds, ps in reversed(cfgs):
+                c.sync()
+                ref_img, ref_ids, _ = orc.render(scene, ps, w, h, flags=orc.TRAVERSE_FAST)
+                assert np.array_equal(c.hit_ids(), ref_ids), (rep, flags, tracer)
+                assert np.array_equal(c.image().view(np.uint32), ref_img.view(np.uint32)), (rep, flags, tracer)
+    finally:
+        a.close(); b.close()
