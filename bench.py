@@ -117,6 +117,46 @@ def start_watchdog(phase, world, seconds):
     return t
 
 
+def install_term_handler(phase, world):
+    """A launcher that loses one rank ends the others with SIGTERM (torch.distributed.run does).  Rank 0 then says on stdout
+    what it knows: the finished line if only the image gather was outstanding, else ONE JSON line with "error", its phase
+    and the time, so that a run that died on another rank does not end with an empty stdout."""
+    import signal
+    import threading
+
+    def report_and_exit():
+        if phase.rank == 0 and phase.name != "done":
+            pending = phase.pending
+            if pending is not None:
+                pending["config"]["gather"] = f"failed: terminated in phase {phase.name}"
+                pending["config"]["gather_ms"], pending["config"]["gather_check"] = None, None
+                print(json.dumps(pending), flush=True)
+                os._exit(0)
+            print(json.dumps({"error": "terminated", "rank": 0, "n_gpus": world, "phase": phase.name,
+                              "after_s": round(time.time() - phase.t0, 1)}), flush=True)
+        os._exit(143)
+
+    # A Python signal handler only runs when the main thread is back in the interpreter, and the main thread of a rank that
+    # is being terminated sits in a collective or a stream wait.  The interpreter's C-level handler, however, runs at once
+    # in whichever thread gets the signal and writes the signal number to the wake-up descriptor: a thread of its own
+    # reads that pipe and reports.
+    try:
+        r, w = os.pipe()
+        os.set_blocking(w, False)
+        signal.signal(signal.SIGTERM, lambda signum, frame: report_and_exit())
+        signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+    except (ValueError, OSError):      # not the main thread (imported by a test)
+        return
+
+    def wait_for_term():
+        while True:
+            b = os.read(r, 1)
+            if b and b[0] == signal.SIGTERM:
+                report_and_exit()
+
+    threading.Thread(target=wait_for_term, daemon=True).start()
+
+
 def rank_timeout_s():
     return float(os.environ.get("CRT_BENCH_RANK_TIMEOUT", "420"))      # below the launcher's limit, which is below the driver's (600 s in round 2)
 
@@ -373,6 +413,7 @@ def main():
     phase = Phase(rank)
     if world > 1:
         start_watchdog(phase, world, rank_timeout_s())
+        install_term_handler(phase, world)
     # CRT_BENCH_REHEARSE=1: every rank on GPU 0 and gloo instead of RCCL, to rehearse the multi-rank path of this script
     # on a one-GPU box (RCCL refuses two ranks on one device); never set by the driver
     rehearse = os.environ.get("CRT_BENCH_REHEARSE", "") == "1"

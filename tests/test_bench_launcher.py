@@ -159,3 +159,27 @@ def test_other_ranks_end_quietly_with_exit_code_0_when_the_gather_hangs_after_th
     env["CRT_BENCH_GATHER_TIMEOUT"] = "1"
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=env)
     assert r.returncode == 0 and _json_lines(r.stdout) == [] and "rank 3 stuck in phase first_gather" in r.stderr
+
+
+def test_rank_0_reports_its_phase_when_the_launcher_terminates_it(tmp_path):
+    # torch.distributed.run ends the surviving ranks with SIGTERM when one rank dies: rank 0 leaves one JSON line behind
+    import signal
+    import subprocess
+    import time
+    code = (
+        "import os, sys, time\n"
+        "sys.argv = ['bench.py']\n"
+        "import importlib.util\n"
+        "spec = importlib.util.spec_from_file_location('crt_bench', %r)\n"
+        "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+        "ph = m.Phase(0); m.install_term_handler(ph, 8); ph.set('timed_steps')\n"
+        "print('ready', file=sys.stderr, flush=True)\n"
+        "import ctypes; ctypes.CDLL(None).sleep(30)\n" % os.path.join(ROOT, "bench.py"))      # the main thread blocked in C, as in a collective
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")}
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    assert p.stderr.readline().strip() == "ready"
+    p.send_signal(signal.SIGTERM)
+    out, _ = p.communicate(timeout=30)
+    assert p.returncode == 143
+    lines = _json_lines(out)
+    assert len(lines) == 1 and lines[0]["error"] == "terminated" and lines[0]["phase"] == "timed_steps" and lines[0]["n_gpus"] == 8
